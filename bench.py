@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Benchmark of the NeRF ray-chunk renderer on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+One *step* = one pass of the hot path over one frame of synthetic rays: the 800x800 Blender-lego
+camera at 64 coarse + 128 fine samples (BASELINE.json configs[2]; configs[3] is the same frame over
+N GPUs). The frame's 640,000 rays are resident in HBM before the timed region, cut into N contiguous
+shards (one process per GPU), rendered in the reference's 32,768-ray chunks
+(nerf/yaml/lego_blender200k_fullres:6) and gathered to rank 0 with one RCCL gather per frame - the
+total work is fixed, so scaling is "strong". Weights are seeded synthetic tensors of the reference
+architecture (no checkpoint or dataset exists offline).
+
+1 ray-sample = 1 MLP point evaluation; a 64+128 ray costs 64 + 192 = 256 of them
+(1,186,816 FLOP each). `value` is the whole-job rate over all N GPUs.
+The roofline object prices the fused encode+MLP kernel against the dense fp32 MFMA peak
+(157.3 TFLOP/s, MI355X_MICROARCH.md) using HIP events recorded on its launch stream inside the
+timed region. The cpu_baseline object times the CPU oracle (numpy port, oracle/nerf_oracle.py) on
+a bounded sample of the same rays; it is reported next to the GPU number, never used by it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_EVAL = 1186816          # 2 * 593,408 MACs
+PEAK_FP32_MFMA_TFLOPS = 157.3    # dense v_mfma_f32_32x32x2_f32 peak, MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (H, W, N_samples, N_importance, ndc, white_bkgd)
+    "lego_800x800_64c+128f": (800, 800, 64, 128, False, True),
+    "lego_400x400_64c": (400, 400, 64, 0, False, True),
+    "fern_1008x756_ndc_64c+128f": (756, 1008, 64, 128, True, False),
+}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--workload", default="lego_800x800_64c+128f", choices=sorted(WORKLOADS))
+    p.add_argument("--chunk", type=int, default=32768)
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(sample_rays, sd_c, sd_f, Sc, Si, white, target_s):
+    """Time the CPU oracle on a bounded sample of the workload's rays (rank 0, N=1 only)."""
+    from oracle import nerf_oracle as O
+    net_c = O.NeRF(8, 256, 63, 27, 4, (4,), True, sd_c)
+    net_f = O.NeRF(8, 256, 63, 27, 4, (4,), True, sd_f)
+    q = O.make_query_fn(O.get_embedder(10)[0], O.get_embedder(4)[0])
+    kw = dict(N_samples=Sc, N_importance=Si, network_fine=net_f if Si else None, white_bkgd=white)
+    probe = min(256, len(sample_rays))
+    t0 = time.perf_counter()
+    O.render_rays(sample_rays[:probe], net_c, q, **kw)
+    dt = time.perf_counter() - t0
+    n = int(min(len(sample_rays), max(probe, target_s / max(dt, 1e-6) * probe)))
+    n = max(64, (n // 64) * 64)
+    t0 = time.perf_counter()
+    ret = O.batchify_rays(sample_rays[:n], 4096, network_fn=net_c, network_query_fn=q, **kw)
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [os.cpu_count()])
+    except Exception:
+        cores = os.cpu_count()
+    evals = n * (Sc + (Sc + Si if Si else 0))
+    return ret, n, {"value": evals / dt, "unit": "ray-samples/s", "cores": int(cores), "kind": "port",
+                    "sample": f"{n} rays of the same frame ({evals} MLP evals) in {dt:.1f} s, numpy/OpenBLAS "
+                              f"oracle on the host CPU ({os.cpu_count()} logical cores visible); "
+                              f"{n / dt:.0f} rays/s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import nerf_projects_amd as N
+    from nerf_projects_amd import synthetic
+
+    H, W, Sc, Si, ndc, white = WORKLOADS[args.workload]
+    if ndc:
+        K, c2w, near, far = synthetic.fern_camera(H, W)
+    else:
+        K, c2w, near, far = synthetic.lego_camera(H, W)
+    sd_c, sd_f = synthetic.synthetic_pair(0)
+    mk = dict(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True)
+    net_c = N.NeRF(**mk).load_state_dict(sd_c)
+    net_f = N.NeRF(**mk).load_state_dict(sd_f)
+    query = N.make_network_query_fn(N.get_embedder(10, 0)[0], N.get_embedder(4, 0)[0])
+    kw = dict(network_fn=net_c, network_query_fn=query, N_samples=Sc, N_importance=Si,
+              network_fine=net_f if Si else None, white_bkgd=white, perturb=0., raw_noise_std=0.)
+
+    # inputs resident in HBM before the timed region: the packed ray record of this rank's shard
+    packed, sh = N.pack_rays(H, W, K, c2w=c2w, ndc=ndc, near=near, far=far, use_viewdirs=True, device="cuda")
+    n_total = packed.shape[0]
+    lo, hi = N.shard_bounds(n_total, world, rank)
+    shard = packed[lo:hi].contiguous()
+    del packed
+    evals_per_ray = Sc + (Sc + Si if Si else 0)
+    ctx = N.get_context()
+
+    def step():
+        ret = N.batchify_rays(shard, args.chunk, **kw)
+        local_out = {k: ret[k] for k in ("rgb_map", "disp_map", "acc_map")}
+        if world > 1:
+            return N.gather_frame(local_out, n_total)
+        return local_out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    t0 = time.perf_counter()
+    frame = None
+    for _ in range(args.steps):
+        frame = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    mlp_ms, mlp_launches, mlp_points = ctx.profile_read(reset=True)
+    t = torch.tensor([dt, mlp_ms, float(mlp_points), float(mlp_launches)], device="cuda", dtype=torch.float64)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+        mlp_ms_sum, pts_sum, launches_sum = float(t[1]), float(t[2]), float(t[3])
+    else:
+        mlp_ms_sum, pts_sum, launches_sum = mlp_ms, float(mlp_points), float(mlp_launches)
+
+    if rank == 0:
+        total_evals = n_total * evals_per_ray * args.steps
+        value = total_evals / dt
+        # dominant kernel: algorithmic FLOP per launch / average launch duration (HIP events, per GPU)
+        flop_per_launch = pts_sum / max(launches_sum, 1) * FLOP_PER_EVAL
+        avg_launch_s = mlp_ms_sum / max(launches_sum, 1) * 1e-3
+        achieved = flop_per_launch / max(avg_launch_s, 1e-12) / 1e12
+        out = {
+            "metric": "ray_samples_per_sec", "value": value, "unit": "ray-samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "rays_per_frame": n_total, "N_samples": Sc, "N_importance": Si,
+                       "evals_per_ray": evals_per_ray, "chunk": args.chunk, "netdepth": 8, "netwidth": 256,
+                       "parallelism": f"ray-shard x{world} + gather" if world > 1 else "single GPU"},
+            "rays_per_sec": n_total * args.steps / dt,
+            "ray_samples_per_sec_per_gpu": value / world,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "nerf_mlp_kernel<rays>", "launches": int(launches_sum),
+                         "avg_launch_ms": avg_launch_s * 1e3, "flop_per_launch": flop_per_launch,
+                         "kernel_time_share": mlp_ms_sum * 1e-3 / world / dt},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            # same rays, spread over the whole frame so empty, grazing and opaque rays are all present
+            idx = np.linspace(0, n_total - 1, 4096).astype(np.int64)
+            sample = shard[torch.from_numpy(idx).cuda()].cpu().numpy()
+            ref, n_used, cb = cpu_baseline(sample, sd_c, sd_f, Sc, Si, white, args.cpu_seconds)
+            out["cpu_baseline"] = cb
+            got = frame["rgb_map"][torch.from_numpy(idx[:n_used]).cuda()].cpu().numpy()
+            err = np.abs(got - ref["rgb_map"]).max(-1)
+            mse = float(np.mean((got - ref["rgb_map"]) ** 2))
+            out["parity"] = {"rays": int(n_used), "rgb_linf": float(err.max()), "rgb_p99": float(np.quantile(err, .99)),
+                             "rgb_median": float(np.median(err)), "rays_above_1e-4": int((err > 1e-4).sum()),
+                             "psnr_vs_cpu_oracle_db": (float(-10 * np.log10(mse)) if mse > 0 else float("inf"))}
+            if Si:
+                e0 = np.abs(frame_rgb0(N, shard, idx[:n_used], kw) - ref["rgb0"]).max()
+                out["parity"]["rgb0_linf"] = float(e0)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def frame_rgb0(N, shard, idx, kw):
+    """Coarse-pass colours of the sampled rays (the well-conditioned half of the parity report)."""
+    rays = shard[torch.from_numpy(idx).cuda()].contiguous()
+    return N.batchify_rays(rays, 32768, **kw)["rgb0"].cpu().numpy()
+
+
+if __name__ == "__main__":
+    main()

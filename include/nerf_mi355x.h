@@ -1,0 +1,182 @@
+/*
+ * nerf_mi355x.h - C ABI of the MI355X-native NeRF ray-chunk renderer.
+ *
+ * The reference (isaacchunn/nerf-projects, nerf/) has no FFI or plugin layer on this
+ * path: its "operator API" is the set of Python signatures in notebook cells 8-12/15 of
+ * nerf/nerf.ipynb plus nerf/nerf.py, nerf/embedder.py and nerf/nerf_helpers.py
+ * (SURVEY.md section 8b). Each entry point below states the reference callable it
+ * replaces; nerf-projects_amd/host.py binds them with ctypes under the reference's own
+ * names and signatures, and INTEGRATION.md shows the stub a maintainer would add.
+ *
+ * Conventions
+ *   - Every function returns 0 on success or a negative NERF_E_* code;
+ *     nerf_last_error() returns a thread-local message for the last failure.
+ *   - Pointers marked [dev] are device (HBM) addresses on the context's GPU; [host]
+ *     are ordinary host addresses. All arrays are dense row-major fp32.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream). Calls
+ *     enqueue work and return; they do not synchronise. Outputs are complete when the
+ *     stream reaches the point after the call (the reference is synchronous only
+ *     because eager PyTorch on one stream is).
+ *   - One context per GPU. A context owns the packed weights and a workspace that
+ *     grows on demand; it is not thread-safe, use one per host thread.
+ *   - No CPU fallback exists: without a gfx950 device nerf_ctx_create fails.
+ */
+#ifndef NERF_MI355X_H
+#define NERF_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_OK 0
+#define NERF_E_INVALID (-1)     /* bad argument / unsupported configuration */
+#define NERF_E_HIP (-2)         /* a HIP runtime call failed                */
+#define NERF_E_STATE (-3)       /* e.g. weights of a slot not loaded        */
+#define NERF_E_NOMEM (-4)
+
+#define NERF_MAX_SKIPS 8
+#define NERF_SLOT_COARSE 0      /* network_fn   (nerf.ipynb:887-889) */
+#define NERF_SLOT_FINE 1        /* network_fine (nerf.ipynb:892-896) */
+#define NERF_NUM_SLOTS 16
+
+typedef struct nerf_ctx nerf_ctx;
+
+/* Constructor arguments of the reference NeRF module (nerf/nerf.py:9). */
+typedef struct nerf_arch {
+    int32_t D;                  /* trunk depth, netdepth                          */
+    int32_t W;                  /* trunk width, netwidth (this build: 256 only)   */
+    int32_t input_ch;           /* 3 + 6*multires (63), or 3 for i_embed == -1    */
+    int32_t input_ch_views;     /* 3 + 6*multires_views (27), or 3                */
+    int32_t output_ch;          /* 4, or 5 when N_importance > 0 (nerf.ipynb:885) */
+    int32_t n_skips;
+    int32_t skips[NERF_MAX_SKIPS];
+    int32_t use_viewdirs;
+} nerf_arch;
+
+/* Library / device ------------------------------------------------------------------ */
+
+const char* nerf_last_error(void);
+const char* nerf_version(void);
+/* Number of visible HIP devices, or a negative error. */
+int nerf_device_count(void);
+
+/* Create a context on HIP device `device` (must be gfx950). */
+int nerf_ctx_create(int device, nerf_ctx** out);
+void nerf_ctx_destroy(nerf_ctx* ctx);
+
+/* Weights ---------------------------------------------------------------------------
+ * Replaces NeRF.__init__ + load_state_dict (nerf/nerf.py:9-55; checkpoint reload at
+ * nerf.ipynb:927-935). `tensors` are host pointers to the state_dict entries in this
+ * order, each exactly as PyTorch stores it (weight [out,in] row-major, bias [out]):
+ *   pts_linears.0.weight, pts_linears.0.bias, ..., pts_linears.{D-1}.weight, .bias,
+ *   views_linears.0.weight, views_linears.0.bias,
+ *   then if use_viewdirs: feature_linear.{weight,bias}, alpha_linear.{weight,bias},
+ *                         rgb_linear.{weight,bias}
+ *        else:            output_linear.{weight,bias}
+ * The weights are repacked once into the MFMA fragment stream the kernel consumes.
+ */
+int nerf_load_weights(nerf_ctx* ctx, int slot, const nerf_arch* arch,
+                      const float* const* tensors /*[host]*/, int n_tensors);
+/* Expected tensor count for an architecture (2*D + 2 + (use_viewdirs ? 6 : 2)). */
+int nerf_num_weight_tensors(const nerf_arch* arch);
+
+/* Stage entry points (each backs one reference callable) --------------------------- */
+
+/* Embedder.embed / get_embedder (nerf/embedder.py:72-80, 82-116).
+ * x [n,3] -> out [n, 3+6*multires]; multires == 0 is the i_embed == -1 identity. */
+int nerf_embed(nerf_ctx* ctx, const float* x /*[dev]*/, int64_t n, int multires,
+               float* out /*[dev]*/, void* stream);
+
+/* NeRF.forward (nerf/nerf.py:57-111) on already-encoded rows
+ * x [B, input_ch + input_ch_views] -> out [B, out_ch] where out_ch is 4 with viewdirs
+ * and arch.output_ch without. */
+int nerf_mlp_forward(nerf_ctx* ctx, int slot, const float* x /*[dev]*/, int64_t B,
+                     float* out /*[dev]*/, void* stream);
+
+/* run_network (nerf.ipynb:790-855) with embed_fn/embeddirs_fn = get_embedder(multires /
+ * multires_views): pts [n_rays*n_samples,3], viewdirs [n_rays,3] (NULL when the model
+ * does not use them) -> out [n_rays*n_samples, out_ch]. Encoding, the per-sample
+ * broadcast of viewdirs and the MLP are fused; netchunk does not exist (results are
+ * independent of it). */
+int nerf_run_network(nerf_ctx* ctx, int slot, const float* pts /*[dev]*/,
+                     const float* viewdirs /*[dev]*/, int64_t n_rays, int64_t n_samples,
+                     float* out /*[dev]*/, void* stream);
+
+/* raw2outputs (nerf.ipynb:254-349). raw [N,S,C] (C >= 4; channels 0-2 rgb logits,
+ * 3 sigma), z_vals [N,S], rays_d [N,3], noise [N,S] or NULL (already scaled by
+ * raw_noise_std - the caller owns the RNG). Any output pointer may be NULL. */
+int nerf_raw2outputs(nerf_ctx* ctx, const float* raw /*[dev]*/, int C,
+                     const float* z_vals /*[dev]*/, const float* rays_d /*[dev]*/,
+                     const float* noise /*[dev]*/, int white_bkgd, int64_t N, int S,
+                     float* rgb_map /*[dev] [N,3]*/, float* disp_map /*[dev] [N]*/,
+                     float* acc_map /*[dev] [N]*/, float* weights /*[dev] [N,S]*/,
+                     float* depth_map /*[dev] [N]*/, void* stream);
+
+/* sample_pdf (nerf/nerf_helpers.py:372-439). bins [N,M], weights [N,M-1],
+ * u [N,n_samples] or NULL for det=True (u = linspace(0,1,n_samples)) -> out [N,n_samples]. */
+int nerf_sample_pdf(nerf_ctx* ctx, const float* bins /*[dev]*/, const float* weights /*[dev]*/,
+                    const float* u /*[dev]*/, int64_t N, int M, int n_samples,
+                    float* out /*[dev]*/, void* stream);
+
+/* The ray-chunk renderer ------------------------------------------------------------
+ * render_rays (nerf.ipynb:359-492) for one chunk of rays, all stages on the device with
+ * no host synchronisation: stratified depths -> encode+MLP (coarse) -> composite ->
+ * sample_pdf -> merge/sort -> encode+MLP (fine) -> composite -> z_std.
+ */
+typedef struct nerf_render_args {
+    const float* rays;          /* [dev] [N, ray_stride]: o(3) d(3) near far [viewdir(3)]
+                                   exactly as render() packs it (nerf.ipynb:622-629)  */
+    int64_t n_rays;
+    int32_t ray_stride;         /* 8 or 11 (floats per ray)                            */
+    int32_t N_samples;          /* S_c                                                 */
+    int32_t N_importance;       /* S_i, 0 disables the fine pass                       */
+    int32_t slot_coarse;        /* network_fn                                          */
+    int32_t slot_fine;          /* network_fine, or -1 to reuse network_fn (:471)      */
+    int32_t lindisp;
+    int32_t white_bkgd;
+    int32_t perturb;            /* perturb > 0: t_rand must be given; u_rand replaces
+                                   the deterministic linspace (det = perturb == 0)     */
+    const float* t_rand;        /* [dev] [N,S_c] uniforms for stratified jitter or NULL */
+    const float* u_rand;        /* [dev] [N,S_i] uniforms for sample_pdf or NULL        */
+    const float* noise0;        /* [dev] [N,S_c] sigma noise (scaled) coarse, or NULL   */
+    const float* noise;         /* [dev] [N,S_c+S_i] sigma noise fine pass, or NULL     */
+    /* outputs, any may be NULL */
+    float* rgb_map;             /* [dev] [N,3] last pass                               */
+    float* disp_map;            /* [dev] [N]                                           */
+    float* acc_map;             /* [dev] [N]                                           */
+    float* raw;                 /* [dev] [N,S_last,out_ch] (retraw)                    */
+    float* rgb0;                /* [dev] [N,3] coarse pass (N_importance > 0)          */
+    float* disp0;               /* [dev] [N]                                           */
+    float* acc0;                /* [dev] [N]                                           */
+    float* z_std;               /* [dev] [N]                                           */
+    /* optional intermediates for stage-wise parity */
+    float* z_vals_coarse;       /* [dev] [N,S_c]                                       */
+    float* weights_coarse;      /* [dev] [N,S_c]                                       */
+    float* z_samples;           /* [dev] [N,S_i]                                       */
+    float* z_vals_fine;         /* [dev] [N,S_c+S_i]                                   */
+    float* weights_fine;        /* [dev] [N,S_c+S_i]                                   */
+    float* depth_map;           /* [dev] [N] last pass                                 */
+    const float* z_vals_fine_in;/* [dev] [N,S_c+S_i] inject fine depths (skips sampling) */
+    void* stream;
+} nerf_render_args;
+
+int nerf_render_rays(nerf_ctx* ctx, const nerf_render_args* args);
+
+/* Measurement hooks ------------------------------------------------------------------
+ * Accumulated device time of the dominant kernel (the fused encode+MLP kernel),
+ * measured with HIP events recorded on the launch stream around every launch while
+ * profiling is enabled. nerf_profile_read synchronises those events. */
+int nerf_profile_enable(nerf_ctx* ctx, int on);
+int nerf_profile_read(nerf_ctx* ctx, double* mlp_ms, int64_t* mlp_launches,
+                      int64_t* mlp_points, int reset);
+
+/* Bytes of device workspace currently held by the context. */
+int64_t nerf_workspace_bytes(nerf_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_MI355X_H */

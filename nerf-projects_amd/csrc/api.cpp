@@ -1,0 +1,464 @@
+// C ABI of libnerf_mi355x.so (declared in include/nerf_mi355x.h): context, weights,
+// workspace, the stage entry points and the render_rays pipeline. Host code only; every
+// device function lives in mlp_kernel.hip / ray_kernels.hip.
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+#include "nerf_internal.h"
+
+namespace nerf {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace nerf
+
+using namespace nerf;
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return NERF_E_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+struct nerf_ctx {
+    int device = 0;
+    PackedNet nets[NERF_NUM_SLOTS];
+    char* ws = nullptr;          // workspace arena
+    size_t ws_bytes = 0;
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per MLP launch
+    std::vector<hipEvent_t> pool;
+    int64_t prof_points = 0;
+    double prof_ms = 0.0;
+    int64_t prof_launches = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int ensure_workspace(nerf_ctx* c, size_t bytes) {
+    if (bytes <= c->ws_bytes) return NERF_OK;
+    // growing is rare (first call at a given chunk size); it synchronises the device
+    if (c->ws) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(c->ws));
+        c->ws = nullptr;
+        c->ws_bytes = 0;
+    }
+    const size_t want = bytes + bytes / 8;
+    hipError_t e = hipMalloc((void**)&c->ws, want);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu) for the render workspace failed: %s", want, hipGetErrorString(e));
+        return NERF_E_NOMEM;
+    }
+    c->ws_bytes = want;
+    return NERF_OK;
+}
+
+struct Arena {
+    char* base;
+    size_t off = 0;
+    explicit Arena(char* b) : base(b) {}
+    float* take(size_t n_floats) {
+        float* p = (float*)(base + off);
+        off += (n_floats * sizeof(float) + 255) & ~(size_t)255;
+        return p;
+    }
+};
+size_t arena_bytes(std::initializer_list<size_t> float_counts) {
+    size_t t = 0;
+    for (size_t n : float_counts) t += (n * sizeof(float) + 255) & ~(size_t)255;
+    return t;
+}
+
+int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net, int mode, hipStream_t s) {
+    a.stream = net.d_stream;
+    a.bias = net.d_bias;
+    a.n_chunks = net.n_chunks;
+    a.n_bias_tiles = net.n_bias_tiles;
+    a.D = net.arch.D;
+    a.skip_in_mask = net.skip_in_mask;
+    a.use_viewdirs = net.arch.use_viewdirs;
+    a.out_ch = net.out_ch;
+    a.in_ch = net.arch.input_ch;
+    a.in_ch_views = net.arch.input_ch_views;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) {
+        for (hipEvent_t* e : {&e0, &e1}) {
+            if (!c->pool.empty()) {
+                *e = c->pool.back();
+                c->pool.pop_back();
+            } else {
+                HIP_TRY(hipEventCreate(e));
+            }
+        }
+        HIP_TRY(hipEventRecord(e0, s));
+    }
+    HIP_TRY(launch_mlp(a, mode, s));
+    if (c->profiling) {
+        HIP_TRY(hipEventRecord(e1, s));
+        c->events.emplace_back(e0, e1);
+        c->prof_points += a.n_points;
+    }
+    return NERF_OK;
+}
+
+const PackedNet* get_net(nerf_ctx* c, int slot) {
+    if (slot < 0 || slot >= NERF_NUM_SLOTS) {
+        set_error("slot %d out of range [0,%d)", slot, NERF_NUM_SLOTS);
+        return nullptr;
+    }
+    if (!c->nets[slot].loaded) {
+        set_error("no weights loaded in slot %d", slot);
+        return nullptr;
+    }
+    return &c->nets[slot];
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* nerf_last_error(void) { return g_err; }
+const char* nerf_version(void) { return "nerf_mi355x 0.1 (gfx950, fp32 MFMA)"; }
+
+int nerf_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return NERF_E_HIP;
+    }
+    return n;
+}
+
+int nerf_num_weight_tensors(const nerf_arch* a) {
+    if (!a) return NERF_E_INVALID;
+    return 2 * a->D + 2 + (a->use_viewdirs ? 6 : 2);
+}
+
+int nerf_ctx_create(int device, nerf_ctx** out) {
+    if (!out) {
+        set_error("nerf_ctx_create: out is NULL");
+        return NERF_E_INVALID;
+    }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s); this library has no CPU fallback",
+                  e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return NERF_E_HIP;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (%d visible)", device, n);
+        return NERF_E_INVALID;
+    }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; the kernels are built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return NERF_E_INVALID;
+    }
+    nerf_ctx* c = new (std::nothrow) nerf_ctx();
+    if (!c) return NERF_E_NOMEM;
+    c->device = device;
+    *out = c;
+    return NERF_OK;
+}
+
+void nerf_ctx_destroy(nerf_ctx* c) {
+    if (!c) return;
+    DeviceGuard g(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& n : c->nets) {
+        if (n.d_stream) (void)hipFree(n.d_stream);
+        if (n.d_bias) (void)hipFree(n.d_bias);
+    }
+    if (c->ws) (void)hipFree(c->ws);
+    for (auto& p : c->events) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    delete c;
+}
+
+int nerf_load_weights(nerf_ctx* c, int slot, const nerf_arch* arch, const float* const* tensors, int n_tensors) {
+    if (!c || !arch || !tensors) {
+        set_error("nerf_load_weights: NULL argument");
+        return NERF_E_INVALID;
+    }
+    if (slot < 0 || slot >= NERF_NUM_SLOTS) {
+        set_error("slot %d out of range [0,%d)", slot, NERF_NUM_SLOTS);
+        return NERF_E_INVALID;
+    }
+    DeviceGuard g(c->device);
+    float *hs = nullptr, *hb = nullptr;
+    int nc = 0, nbt = 0, out_ch = 4;
+    uint32_t mask = 0;
+    int rc = pack_weights(*arch, tensors, n_tensors, &hs, &nc, &hb, &nbt, &mask, &out_ch);
+    if (rc != NERF_OK) return rc;
+    PackedNet& net = c->nets[slot];
+    // the previous stream of this slot may still be in use by enqueued work
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess && net.d_stream) e = hipFree(net.d_stream);
+    if (e == hipSuccess && net.d_bias) e = hipFree(net.d_bias);
+    net = PackedNet{};
+    if (e == hipSuccess) e = hipMalloc((void**)&net.d_stream, (size_t)nc * kChunkBytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&net.d_bias, (size_t)nbt * kBiasTileFloats * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(net.d_stream, hs, (size_t)nc * kChunkBytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(net.d_bias, hb, (size_t)nbt * kBiasTileFloats * sizeof(float), hipMemcpyHostToDevice);
+    free(hs);
+    free(hb);
+    if (e != hipSuccess) {
+        set_error("uploading packed weights failed: %s", hipGetErrorString(e));
+        return NERF_E_HIP;
+    }
+    net.arch = *arch;
+    net.n_chunks = nc;
+    net.n_bias_tiles = nbt;
+    net.skip_in_mask = mask;
+    net.out_ch = out_ch;
+    net.loaded = true;
+    return NERF_OK;
+}
+
+int nerf_embed(nerf_ctx* c, const float* x, int64_t n, int multires, float* out, void* stream) {
+    if (!c || !x || !out || n < 0 || multires < 0 || multires > 16) {
+        set_error("nerf_embed: invalid argument");
+        return NERF_E_INVALID;
+    }
+    DeviceGuard g(c->device);
+    HIP_TRY(launch_embed(x, n, multires, out, (hipStream_t)stream));
+    return NERF_OK;
+}
+
+int nerf_mlp_forward(nerf_ctx* c, int slot, const float* x, int64_t B, float* out, void* stream) {
+    if (!c || !x || !out || B < 0) {
+        set_error("nerf_mlp_forward: invalid argument");
+        return NERF_E_INVALID;
+    }
+    const PackedNet* net = get_net(c, slot);
+    if (!net) return NERF_E_STATE;
+    DeviceGuard g(c->device);
+    MlpLaunch a{};
+    a.n_points = B;
+    a.samples_per_ray = 1;
+    a.x = x;
+    a.x_ld = net->arch.input_ch + net->arch.input_ch_views;
+    a.out = out;
+    return run_mlp(c, a, *net, kInputEmbedded, (hipStream_t)stream);
+}
+
+int nerf_run_network(nerf_ctx* c, int slot, const float* pts, const float* viewdirs, int64_t n_rays,
+                     int64_t n_samples, float* out, void* stream) {
+    if (!c || !pts || !out || n_rays < 0 || n_samples <= 0) {
+        set_error("nerf_run_network: invalid argument");
+        return NERF_E_INVALID;
+    }
+    const PackedNet* net = get_net(c, slot);
+    if (!net) return NERF_E_STATE;
+    if (net->arch.use_viewdirs && !viewdirs) {
+        set_error("nerf_run_network: the model uses viewdirs but none were given");
+        return NERF_E_INVALID;
+    }
+    DeviceGuard g(c->device);
+    MlpLaunch a{};
+    a.n_points = n_rays * n_samples;
+    a.samples_per_ray = n_samples;
+    a.pts = pts;
+    a.viewdirs = net->arch.use_viewdirs ? viewdirs : nullptr;
+    a.out = out;
+    return run_mlp(c, a, *net, kInputPoints, (hipStream_t)stream);
+}
+
+int nerf_raw2outputs(nerf_ctx* c, const float* raw, int C, const float* z_vals, const float* rays_d,
+                     const float* noise, int white_bkgd, int64_t N, int S, float* rgb_map, float* disp_map,
+                     float* acc_map, float* weights, float* depth_map, void* stream) {
+    if (!c || !raw || !z_vals || !rays_d || C < 4 || N < 0 || S < 1) {
+        set_error("nerf_raw2outputs: invalid argument (C >= 4, S >= 1 required)");
+        return NERF_E_INVALID;
+    }
+    DeviceGuard g(c->device);
+    HIP_TRY(launch_composite(raw, C, z_vals, rays_d, 3, noise, white_bkgd, N, S, rgb_map, disp_map, acc_map, weights,
+                             depth_map, (hipStream_t)stream));
+    return NERF_OK;
+}
+
+int nerf_sample_pdf(nerf_ctx* c, const float* bins, const float* weights, const float* u, int64_t N, int M,
+                    int n_samples, float* out, void* stream) {
+    if (!c || !bins || !weights || !out || N < 0 || M < 2 || n_samples < 1 || M > 4096 || n_samples > 4096) {
+        set_error("nerf_sample_pdf: invalid argument (2 <= M <= 4096, 1 <= n_samples <= 4096)");
+        return NERF_E_INVALID;
+    }
+    DeviceGuard g(c->device);
+    HIP_TRY(launch_sample_pdf(bins, weights, M - 1, 0, nullptr, u, N, M, n_samples, out, nullptr, nullptr,
+                              (hipStream_t)stream));
+    return NERF_OK;
+}
+
+int nerf_render_rays(nerf_ctx* c, const nerf_render_args* r) {
+    if (!c || !r || !r->rays || r->n_rays < 0) {
+        set_error("nerf_render_rays: NULL argument");
+        return NERF_E_INVALID;
+    }
+    const int64_t N = r->n_rays;
+    const int Sc = r->N_samples, Si = r->N_importance, Sf = Sc + Si;
+    if (r->ray_stride != 8 && r->ray_stride != 11) {
+        set_error("ray_stride must be 8 or 11 floats (got %d)", r->ray_stride);
+        return NERF_E_INVALID;
+    }
+    if (Sc < 1 || Si < 0 || Sc > 4096 || Sf > 4096) {
+        set_error("unsupported sample counts N_samples=%d N_importance=%d", Sc, Si);
+        return NERF_E_INVALID;
+    }
+    if (Si > 0 && Sc < 3) {
+        set_error("hierarchical sampling needs N_samples >= 3 (weights[...,1:-1] would be empty)");
+        return NERF_E_INVALID;
+    }
+    if (r->perturb && !r->t_rand) {
+        set_error("perturb > 0 requires t_rand (the caller owns the RNG)");
+        return NERF_E_INVALID;
+    }
+    if (r->perturb && Si > 0 && !r->u_rand && !r->z_vals_fine_in) {
+        set_error("perturb > 0 with N_importance > 0 requires u_rand (det = (perturb == 0))");
+        return NERF_E_INVALID;
+    }
+    if (N * (int64_t)Sf > 0x7fffffffLL) {
+        set_error("chunk too large: n_rays*(N_samples+N_importance) must stay below 2^31");
+        return NERF_E_INVALID;
+    }
+    const PackedNet* nc = get_net(c, r->slot_coarse);
+    if (!nc) return NERF_E_STATE;
+    const PackedNet* nf = nc;
+    if (Si > 0 && r->slot_fine >= 0) {
+        nf = get_net(c, r->slot_fine);
+        if (!nf) return NERF_E_STATE;
+    }
+    for (const PackedNet* n : {nc, nf}) {
+        if (n->arch.use_viewdirs && r->ray_stride < 11) {
+            set_error("the model uses viewdirs but rays carry only %d columns", r->ray_stride);
+            return NERF_E_INVALID;
+        }
+        if (n->out_ch < 4) {
+            set_error("render_rays needs a model with >= 4 output channels (got %d)", n->out_ch);
+            return NERF_E_INVALID;
+        }
+    }
+    if (N == 0) return NERF_OK;
+    DeviceGuard g(c->device);
+    hipStream_t s = (hipStream_t)r->stream;
+    const int Cc = nc->out_ch, Cf = nf->out_ch;
+
+    const size_t nN = (size_t)N;
+    const bool raw_is_coarse = Si == 0;
+    int rc = ensure_workspace(c, arena_bytes({nN * Sc, nN * Sc * Cc, nN * Sc, nN * (Si ? Si : 1),
+                                              nN * (Si ? Sf : 1), nN * (Si ? (size_t)Sf * Cf : 1)}));
+    if (rc != NERF_OK) return rc;
+    Arena ar(c->ws);
+    float* z_c = r->z_vals_coarse ? r->z_vals_coarse : ar.take(nN * Sc);
+    float* raw_c = (raw_is_coarse && r->raw) ? r->raw : ar.take(nN * Sc * Cc);
+    float* w_c = r->weights_coarse ? r->weights_coarse : ar.take(nN * Sc);
+
+    HIP_TRY(launch_stratified(r->rays, r->ray_stride, N, Sc, r->lindisp, r->perturb ? r->t_rand : nullptr, z_c, s));
+    MlpLaunch a{};
+    a.n_points = N * Sc;
+    a.samples_per_ray = Sc;
+    a.rays = r->rays;
+    a.ray_ld = r->ray_stride;
+    a.z_vals = z_c;
+    a.out = raw_c;
+    rc = run_mlp(c, a, *nc, kInputRays, s);
+    if (rc != NERF_OK) return rc;
+    HIP_TRY(launch_composite(raw_c, Cc, z_c, r->rays + 3, r->ray_stride, r->noise0, r->white_bkgd, N, Sc,
+                             Si ? r->rgb0 : r->rgb_map, Si ? r->disp0 : r->disp_map, Si ? r->acc0 : r->acc_map, w_c,
+                             Si ? nullptr : r->depth_map, s));
+    if (Si == 0) return NERF_OK;
+
+    float* z_s = r->z_samples ? r->z_samples : ar.take(nN * Si);
+    float* z_f = r->z_vals_fine ? r->z_vals_fine : ar.take(nN * Sf);
+    float* raw_f = r->raw ? r->raw : ar.take(nN * Sf * Cf);
+    // z_samples from the coarse weights[...,1:-1] over z_vals_mid; merged and sorted with z_vals
+    HIP_TRY(launch_sample_pdf(nullptr, w_c, Sc, 1, z_c, r->perturb ? r->u_rand : nullptr, N, Sc - 1, Si, z_s, z_f,
+                              r->z_std, s));
+    if (r->z_vals_fine_in) {
+        if (r->z_vals_fine) {
+            HIP_TRY(hipMemcpyAsync(z_f, r->z_vals_fine_in, nN * Sf * sizeof(float), hipMemcpyDeviceToDevice, s));
+        } else {
+            z_f = const_cast<float*>(r->z_vals_fine_in);
+        }
+    }
+    MlpLaunch b{};
+    b.n_points = N * Sf;
+    b.samples_per_ray = Sf;
+    b.rays = r->rays;
+    b.ray_ld = r->ray_stride;
+    b.z_vals = z_f;
+    b.out = raw_f;
+    rc = run_mlp(c, b, *nf, kInputRays, s);
+    if (rc != NERF_OK) return rc;
+    HIP_TRY(launch_composite(raw_f, Cf, z_f, r->rays + 3, r->ray_stride, r->noise, r->white_bkgd, N, Sf, r->rgb_map,
+                             r->disp_map, r->acc_map, r->weights_fine, r->depth_map, s));
+    return NERF_OK;
+}
+
+int nerf_profile_enable(nerf_ctx* c, int on) {
+    if (!c) return NERF_E_INVALID;
+    c->profiling = on != 0;
+    return NERF_OK;
+}
+
+int nerf_profile_read(nerf_ctx* c, double* mlp_ms, int64_t* launches, int64_t* points, int reset) {
+    if (!c) return NERF_E_INVALID;
+    DeviceGuard g(c->device);
+    for (auto& p : c->events) {
+        HIP_TRY(hipEventSynchronize(p.second));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+        c->prof_ms += ms;
+        c->prof_launches += 1;
+        c->pool.push_back(p.first);
+        c->pool.push_back(p.second);
+    }
+    c->events.clear();
+    if (mlp_ms) *mlp_ms = c->prof_ms;
+    if (launches) *launches = c->prof_launches;
+    if (points) *points = c->prof_points;
+    if (reset) {
+        c->prof_ms = 0.0;
+        c->prof_launches = 0;
+        c->prof_points = 0;
+    }
+    return NERF_OK;
+}
+
+int64_t nerf_workspace_bytes(nerf_ctx* c) { return c ? (int64_t)c->ws_bytes : 0; }
+
+}  // extern "C"

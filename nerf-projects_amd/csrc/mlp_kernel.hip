@@ -1,0 +1,392 @@
+// Fused positional-encoding + NeRF MLP kernel for gfx950 (MI355X, CDNA4).
+//
+// Replaces, per sample point, Embedder.embed (nerf/embedder.py:72-80), the per-sample
+// viewdir broadcast + concat of run_network (nerf.ipynb:827-843) and NeRF.forward
+// (nerf/nerf.py:57-111). One launch evaluates the whole network for every point; no
+// encoded features or hidden activations ever reach HBM.
+//
+// Mapping to the hardware
+//   * A wavefront owns 32 consecutive points. Activations are kept feature-major in
+//     registers: the 256-wide hidden vector of those 32 points is 8 MFMA 32x32 accumulator
+//     tiles (8 x 16 = 128 registers); a second set of 128 registers receives the next
+//     layer. With `amdgpu_waves_per_eu(1,1)` a wave may use the whole 512-entry unified
+//     VGPR/AGPR file, so both sets, the encoded inputs (32 + 16 registers, kept for the
+//     skip connection) and the operand staging fit without spilling.
+//   * Every product is v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate: bit-for-bit an
+//     fmaf chain, the only MFMA that can hold the 1e-6 stage tolerance). Weights are the A
+//     operand, activations the B operand; because the accumulator layout of one layer is
+//     already the B-operand layout of the next (pack_weights.cpp explains the permutation),
+//     layers chain with no LDS round trip and no cross-lane traffic: the only per-layer
+//     vector work is the ReLU (v_max) that also moves the tile into the operand set.
+//   * Weights (2.4 MB per network) are streamed L2 -> LDS in 32 KiB chunks by LDS-DMA
+//     (`global_load_lds_dwordx4`, 8 wave-instructions per wave per chunk), double-buffered:
+//     chunk c+1 is in flight while the four waves of the workgroup run the 128 MFMAs of
+//     chunk c (8192 matrix-pipe cycles per SIMD), then one barrier. A-fragments are read
+//     with `ds_read_b128` (4 k-steps per lane per read, lane-linear => conflict-free).
+//   * Biases are pre-arranged per accumulator register and read from LDS straight into
+//     the accumulator tile (no MFMA, no VALU).
+//
+// Roofline: 593,408 MAC/point -> 9,464 MFMA per 32 points (98.0 % of them useful; the
+// rest is K/N padding of the 63-, 27-, 1- and 3-wide edges). Bound: fp32 MFMA,
+// 64 cycles per v_mfma_f32_32x32x2_f32 per SIMD, 157.3 TFLOP/s per chip.
+#include "nerf_internal.h"
+
+namespace nerf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ---- weight-stream pipeline ------------------------------------------------------------
+struct Pipe {
+    const char* stream;   // packed chunks in HBM/L2
+    char* lds;            // two chunk buffers
+    int c;                // chunk being consumed
+    int n;                // chunks in the stream
+    int wave;             // wave-uniform
+    int lane;
+};
+
+__device__ __forceinline__ void prefetch_chunk(const Pipe& p, int chunk) {
+    const char* g = p.stream + (size_t)chunk * kChunkBytes + p.wave * 8192 + p.lane * 16;
+    char* l = p.lds + (chunk & 1) * kChunkBytes + p.wave * 8192;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(g + i * 1024), LDS_PTR(l + i * 1024), 16, 0, 0);
+}
+
+// Start consuming chunk p.c: put chunk p.c+1 in flight into the other buffer (free since the
+// barrier that ended chunk p.c-1) and return this lane's fragment base in the current one.
+__device__ __forceinline__ const f32x4* chunk_begin(const Pipe& p) {
+    if (p.c + 1 < p.n) prefetch_chunk(p, p.c + 1);
+    return (const f32x4*)(p.lds + (p.c & 1) * kChunkBytes) + p.lane;
+}
+
+// All waves are done reading chunk p.c and every wave's share of chunk p.c+1 has landed.
+__device__ __forceinline__ void chunk_end(Pipe& p) {
+    __syncthreads();   // hipcc emits s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier here
+    ++p.c;
+}
+
+// A-fragments of one (output tile, k-tile) pair: 4 x ds_read_b128 = 16 k-steps per lane
+struct Frag16 {
+    f32x4 q[4];
+};
+__device__ __forceinline__ Frag16 read_frags(const f32x4* fr, int group) {
+    Frag16 f;
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) f.q[t4] = fr[(group + t4) * 64];
+    return f;
+}
+__device__ __forceinline__ void mma16(f32x16& acc, const Frag16& f, const f32x16& b) {
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+        acc = mfma(f.q[t4][0], b[4 * t4 + 0], acc);
+        acc = mfma(f.q[t4][1], b[4 * t4 + 1], acc);
+        acc = mfma(f.q[t4][2], b[4 * t4 + 2], acc);
+        acc = mfma(f.q[t4][3], b[4 * t4 + 3], acc);
+    }
+}
+// One wave per SIMD has nobody to hide LDS latency behind, so the fragment reads are
+// software-pipelined by hand: the 4 reads of step n+1 are issued before the 16 MFMAs
+// (1024 matrix-pipe cycles) of step n. sched_group_barrier pins that order in the ISA.
+// The first MFMA of a step goes ahead of the next step's reads so that the s_waitcnt hipcc
+// inserts for it (in-order lgkmcnt) only ever waits for reads issued a whole step earlier.
+#define SCHED_READS() __builtin_amdgcn_sched_group_barrier(0x100, 4, 0)
+#define SCHED_MFMAS(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+
+// one k-tile (16 k-steps) against NOT output tiles; groups ordered [ot][t4]
+template <int NOT>
+__device__ __forceinline__ void mma_ktile(f32x16 (&acc)[8], const f32x16& b, const f32x4* fr, int gbase = 0) {
+    Frag16 cur = read_frags(fr, gbase);
+    SCHED_READS();
+#pragma unroll
+    for (int ot = 0; ot < NOT; ++ot) {
+        Frag16 nxt = cur;
+        if (ot + 1 < NOT) nxt = read_frags(fr, gbase + (ot + 1) * 4);
+        mma16(acc[ot], cur, b);
+        if (ot + 1 < NOT) {
+            SCHED_MFMAS(1);
+            SCHED_READS();
+            SCHED_MFMAS(15);
+        } else {
+            SCHED_MFMAS(16);
+        }
+        cur = nxt;
+    }
+}
+
+// NKT k-tiles against ONE output tile; groups ordered [kt][t4]
+template <int NKT>
+__device__ __forceinline__ void mma_row(f32x16& acc, const f32x16 (&b)[8], const f32x4* fr) {
+    Frag16 cur = read_frags(fr, 0);
+    SCHED_READS();
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        Frag16 nxt = cur;
+        if (kt + 1 < NKT) nxt = read_frags(fr, (kt + 1) * 4);
+        mma16(acc, cur, b[kt]);
+        if (kt + 1 < NKT) {
+            SCHED_MFMAS(1);
+            SCHED_READS();
+            SCHED_MFMAS(15);
+        } else {
+            SCHED_MFMAS(16);
+        }
+        cur = nxt;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void load_bias(f32x16 (&acc)[8], const float* bias_lds, int tile, int h) {
+#pragma unroll
+    for (int ot = 0; ot < N; ++ot)
+        acc[ot] = *(const f32x16*)(bias_lds + ((tile + ot) * 2 + h) * 16);
+}
+
+template <int N, bool RELU>
+__device__ __forceinline__ void activate(f32x16 (&dst)[8], const f32x16 (&src)[8]) {
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[t][r] = RELU ? fmaxf(src[t][r], 0.0f) : src[t][r];
+}
+
+// ---- inputs -----------------------------------------------------------------------------
+// Slot maps of the encoded tiles (must match pack_weights.cpp).
+__host__ __device__ constexpr int pe_col_xyz(int s, int h) {
+    return s < 30 ? 3 + 6 * (s / 3) + 3 * h + (s % 3) : (s == 30 ? (h ? 2 : 0) : (h ? -1 : 1));
+}
+__host__ __device__ constexpr int pe_col_dir(int t, int h) {
+    return t < 12 ? 3 + 6 * (t / 3) + 3 * h + (t % 3) : (t == 12 ? (h ? 2 : 0) : (t == 13 ? (h ? -1 : 1) : -1));
+}
+
+// gamma(xyz) and gamma(dir) of one point in the tile layout: half-wave 0 keeps the sines,
+// half-wave 1 the cosines. x*2^k is exact in fp32 (embedder.py:48,61); sincosf is the
+// accurate ocml routine (not v_sin_f32): arguments reach |x|*512.
+__device__ __forceinline__ void encode_point(const float (&p)[3], const float (&d)[3], int h, bool dirs,
+                                             f32x16& x0, f32x16& x1, f32x16& dd) {
+#pragma unroll
+    for (int s = 0; s < 30; ++s) {
+        float sn, cs;
+        sincosf(p[s % 3] * (float)(1 << (s / 3)), &sn, &cs);
+        const float v = h ? cs : sn;
+        if (s < 16) x0[s] = v; else x1[s - 16] = v;
+    }
+    x1[14] = h ? p[2] : p[0];
+    x1[15] = h ? 0.0f : p[1];
+    if (dirs) {
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            float sn, cs;
+            sincosf(d[t % 3] * (float)(1 << (t / 3)), &sn, &cs);
+            dd[t] = h ? cs : sn;
+        }
+        dd[12] = h ? d[2] : d[0];
+        dd[13] = h ? 0.0f : d[1];
+        dd[14] = 0.0f;
+        dd[15] = 0.0f;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) dd[t] = 0.0f;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void load_inputs(const MlpLaunch& a, int64_t pt, int h, f32x16& x0, f32x16& x1,
+                                            f32x16& dd) {
+    if (MODE == kInputEmbedded) {
+        const float* row = a.x + pt * a.x_ld;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int c = h ? pe_col_xyz(s, 1) : pe_col_xyz(s, 0);
+            const float v = (c >= 0 && c < a.in_ch) ? row[c] : 0.0f;
+            if (s < 16) x0[s] = v; else x1[s - 16] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int c = h ? pe_col_dir(t, 1) : pe_col_dir(t, 0);
+            dd[t] = (a.use_viewdirs && c >= 0 && c < a.in_ch_views) ? row[a.in_ch + c] : 0.0f;
+        }
+        return;
+    }
+    float p[3], d[3] = {0.0f, 0.0f, 0.0f};
+    const int64_t ray = pt / a.samples_per_ray;
+    if (MODE == kInputPoints) {
+        p[0] = a.pts[pt * 3 + 0];
+        p[1] = a.pts[pt * 3 + 1];
+        p[2] = a.pts[pt * 3 + 2];
+        if (a.viewdirs) {
+            d[0] = a.viewdirs[ray * 3 + 0];
+            d[1] = a.viewdirs[ray * 3 + 1];
+            d[2] = a.viewdirs[ray * 3 + 2];
+        }
+    } else {
+        // pts = rays_o + rays_d * z (nerf.ipynb:447, :468): product and sum rounded separately
+        const float* r = a.rays + ray * a.ray_ld;
+        const float z = a.z_vals[pt];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[c] = __fadd_rn(r[c], __fmul_rn(r[3 + c], z));
+        if (a.ray_ld > 8) {
+            d[0] = r[a.ray_ld - 3];
+            d[1] = r[a.ray_ld - 2];
+            d[2] = r[a.ray_ld - 1];
+        }
+    }
+    encode_point(p, d, h, a.use_viewdirs != 0, x0, x1, dd);
+}
+
+// ---- the kernel -------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void nerf_mlp_kernel(const MlpLaunch a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* bias_lds = (float*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5;
+
+    Pipe pipe{(const char*)a.stream, smem + kBiasLdsBytes, 0, a.n_chunks, wave, lane};
+    prefetch_chunk(pipe, 0);
+    for (int i = threadIdx.x; i < a.n_bias_tiles * kBiasTileFloats; i += 256) bias_lds[i] = a.bias[i];
+
+    const int64_t tile0 = (int64_t)blockIdx.x * kPointsPerGroup + wave * kPointsPerWave;
+    const int64_t pt_raw = tile0 + (lane & 31);
+    const int64_t pt = pt_raw < a.n_points ? pt_raw : a.n_points - 1;   // clamp: padded lanes recompute the last point
+
+    f32x16 x0, x1, dd;
+    load_inputs<MODE>(a, pt, h, x0, x1, dd);
+    __syncthreads();   // chunk 0 and the bias block are in LDS
+
+    f32x16 hid[8], acc[8];
+
+    // layer 0: gamma(xyz) -> W (nerf.py:70-73)
+    load_bias<8>(acc, bias_lds, 0, h);
+    {
+        const f32x4* fr = chunk_begin(pipe);
+        mma_ktile<8>(acc, x0, fr);
+        chunk_end(pipe);
+        fr = chunk_begin(pipe);
+        mma_ktile<8>(acc, x1, fr);
+        chunk_end(pipe);
+    }
+    activate<8, true>(hid, acc);
+
+    // trunk layers 1..D-1, then (with viewdirs) feature_linear as layer D without ReLU
+    const int n_layers = a.use_viewdirs ? a.D + 1 : a.D;
+    float sigma = 0.0f;
+    for (int i = 1; i < n_layers; ++i) {
+        const bool is_feature = (i == a.D);
+        if (is_feature) {
+            // alpha_linear reads the post-ReLU trunk output before feature_linear (nerf.py:86-89)
+            f32x16 al = *(const f32x16*)(bias_lds + ((8 * a.D) * 2 + h) * 16);
+            const f32x4* fr = chunk_begin(pipe);
+            mma_row<8>(al, hid, fr);
+            chunk_end(pipe);
+            sigma = al[0];   // row 0 lives in register 0 of half-wave 0
+        }
+        load_bias<8>(acc, bias_lds, is_feature ? 8 * a.D + 1 : 8 * i, h);
+        if (!is_feature && ((a.skip_in_mask >> i) & 1)) {
+            // h = cat[input_pts, h] (nerf.py:79-80): the encoded inputs are still in registers
+            const f32x4* fr = chunk_begin(pipe);
+            mma_ktile<8>(acc, x0, fr);
+            chunk_end(pipe);
+            fr = chunk_begin(pipe);
+            mma_ktile<8>(acc, x1, fr);
+            chunk_end(pipe);
+        }
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            const f32x4* fr = chunk_begin(pipe);
+            mma_ktile<8>(acc, hid[kt], fr);
+            chunk_end(pipe);
+        }
+        if (is_feature) activate<8, false>(hid, acc); else activate<8, true>(hid, acc);
+    }
+
+    const bool live = pt_raw < a.n_points;
+    if (a.use_viewdirs) {
+        // views_linears[0] on cat[feature, gamma(dir)] (nerf.py:93-98): 4 output tiles
+        load_bias<4>(acc, bias_lds, 8 * a.D + 9, h);
+#pragma unroll
+        for (int kp = 0; kp < 4; ++kp) {
+            const f32x4* fr = chunk_begin(pipe);
+            mma_ktile<4>(acc, hid[2 * kp], fr, 0);
+            mma_ktile<4>(acc, hid[2 * kp + 1], fr, 16);
+            chunk_end(pipe);
+        }
+        {
+            const f32x4* fr = chunk_begin(pipe);
+            mma_ktile<4>(acc, dd, fr);
+            chunk_end(pipe);
+        }
+        activate<4, true>(hid, acc);
+        // rgb_linear (nerf.py:101)
+        f32x16 rgb = *(const f32x16*)(bias_lds + ((8 * a.D + 13) * 2 + h) * 16);
+        {
+            const f32x4* fr = chunk_begin(pipe);
+            mma_row<4>(rgb, hid, fr);
+            chunk_end(pipe);
+        }
+        if (live && h == 0) {
+            // outputs = cat[rgb, alpha] (nerf.py:106)
+            f32x4 o = {rgb[0], rgb[1], rgb[2], sigma};
+            *(f32x4*)(a.out + pt * 4) = o;
+        }
+    } else {
+        // output_linear (nerf.py:109): rows 0..out_ch-1 of one tile
+        f32x16 o = *(const f32x16*)(bias_lds + ((8 * a.D) * 2 + h) * 16);
+        const f32x4* fr = chunk_begin(pipe);
+        mma_row<8>(o, hid, fr);
+        chunk_end(pipe);
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < a.out_ch) a.out[pt * a.out_ch + row] = o[r];
+            }
+        }
+    }
+}
+
+hipError_t launch_mlp(const MlpLaunch& a, int mode, hipStream_t s) {
+    if (a.n_points <= 0) return hipSuccess;
+    const int64_t groups = (a.n_points + kPointsPerGroup - 1) / kPointsPerGroup;
+    if (groups > 0x7fffffffLL) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)groups), block(256);
+    const size_t lds = kBiasLdsBytes + 2 * kChunkBytes;
+    // 80 KiB of dynamic LDS is above the 64 KiB default cap: raise it once per device and mode
+    static bool raised[64][3] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (mode < 0 || mode > 2) return hipErrorInvalidValue;
+    if (dev < 64 && !raised[dev][mode]) {
+        const void* fn = mode == kInputEmbedded ? (const void*)nerf_mlp_kernel<kInputEmbedded>
+                         : mode == kInputPoints ? (const void*)nerf_mlp_kernel<kInputPoints>
+                                                : (const void*)nerf_mlp_kernel<kInputRays>;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised[dev][mode] = true;
+    }
+    switch (mode) {
+        case kInputEmbedded:
+            hipLaunchKernelGGL(nerf_mlp_kernel<kInputEmbedded>, grid, block, lds, s, a);
+            break;
+        case kInputPoints:
+            hipLaunchKernelGGL(nerf_mlp_kernel<kInputPoints>, grid, block, lds, s, a);
+            break;
+        default:
+            hipLaunchKernelGGL(nerf_mlp_kernel<kInputRays>, grid, block, lds, s, a);
+            break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace nerf

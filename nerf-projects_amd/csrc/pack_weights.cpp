@@ -1,0 +1,245 @@
+// Host-side repacking of a NeRF state_dict (nerf/nerf.py:32-55) into the MFMA fragment
+// stream consumed by the fused encode+MLP kernel (mlp_kernel.hip).
+//
+// Orientation. The kernel computes H_out^T [features x points] = W [out x in] * H_in^T, so
+// a weight matrix is the MFMA *A* operand and activations never leave the accumulator
+// layout: for v_mfma_f32_32x32x2_f32 the D tile holds C[row][col] with col = lane & 31
+// (the point) and row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (the feature), and the B
+// operand of k-step t wants B[k = lane >> 5][col = lane & 31]. Feeding accumulator register
+// t of an activation tile as the B operand therefore contracts over feature
+//     f(tile, t, h) = 32*tile + (t & 3) + 8*(t >> 2) + 4*h,   h = lane >> 5,
+// with no cross-lane movement, provided the A operand of that k-step holds
+// W[out_row = 32*ot + (lane & 31)][f(tile, t, h)]. That permutation is applied here, once.
+//
+// Positional-encoding tiles use their own slot map (see pe_col_*): half-wave h = 0 holds
+// the sines, h = 1 the cosines of the same (frequency, component), so each lane runs one
+// sincosf per slot and keeps the half it owns.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "nerf_internal.h"
+
+namespace nerf {
+
+namespace {
+
+inline int hidden_col(int tile, int t, int h) { return 32 * tile + (t & 3) + 8 * (t >> 2) + 4 * h; }
+
+// Column of gamma(xyz) (nerf/embedder.py:28-65: [x y z | sin f0 xyz | cos f0 xyz | ...]) held
+// by slot s = 16*tile + t of half-wave h, or -1 for padding.
+inline int pe_col_xyz(int s, int h) {
+    if (s < 30) return 3 + 6 * (s / 3) + 3 * h + (s % 3);
+    if (s == 30) return h ? 2 : 0;
+    return h ? -1 : 1;
+}
+
+// Column of gamma(dir) (27 wide) held by slot t of the single direction tile.
+inline int pe_col_dir(int t, int h) {
+    if (t < 12) return 3 + 6 * (t / 3) + 3 * h + (t % 3);
+    if (t == 12) return h ? 2 : 0;
+    if (t == 13) return h ? -1 : 1;
+    return -1;
+}
+
+struct Stream {
+    std::vector<float> data;
+    float* new_chunk() {
+        data.resize(data.size() + kChunkFloats, 0.0f);
+        return data.data() + data.size() - kChunkFloats;
+    }
+};
+
+struct Linear {
+    const float* w;   // [out, in] row-major
+    const float* b;   // [out]
+    int out, in;
+    float at(int r, int c) const { return (r < out && c >= 0 && c < in) ? w[(size_t)r * in + c] : 0.0f; }
+    float bias(int r) const { return r < out ? b[r] : 0.0f; }
+};
+
+// group g of a chunk: 64 lanes x 4 consecutive k-steps
+template <class ColFn>
+void fill_group(float* chunk, int g, const Linear& L, int ot, int t4, ColFn col) {
+    float* dst = chunk + (size_t)g * kGroupFloats;
+    for (int lane = 0; lane < 64; ++lane) {
+        const int row = 32 * ot + (lane & 31), h = lane >> 5;
+        for (int j = 0; j < 4; ++j) dst[lane * 4 + j] = L.at(row, col(4 * t4 + j, h));
+    }
+}
+
+// one k-tile x `n_ot` (<= 8) output tiles: group = ot*4 + t4
+template <class ColFn>
+void chunk_ktile(Stream& s, const Linear& L, int n_ot, ColFn col) {
+    float* c = s.new_chunk();
+    for (int ot = 0; ot < n_ot; ++ot)
+        for (int t4 = 0; t4 < 4; ++t4) fill_group(c, ot * 4 + t4, L, ot, t4, col);
+}
+
+void bias_tiles(std::vector<float>& out, const Linear& L, int n_ot) {
+    for (int ot = 0; ot < n_ot; ++ot)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) out.push_back(L.bias(32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h));
+}
+
+}  // namespace
+
+int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors, float** stream_out,
+                 int* n_chunks, float** bias_out, int* n_bias_tiles, uint32_t* skip_in_mask,
+                 int* out_ch) {
+    if (a.W != kWidth) {
+        set_error("unsupported netwidth W=%d: this build specialises the MLP kernel for W=%d", a.W, kWidth);
+        return NERF_E_INVALID;
+    }
+    if (a.D < 1 || a.D > kMaxDepth) {
+        set_error("unsupported netdepth D=%d (1..%d)", a.D, kMaxDepth);
+        return NERF_E_INVALID;
+    }
+    if (a.input_ch < 3 || a.input_ch > 63 || (a.input_ch - 3) % 6 != 0) {
+        set_error("unsupported input_ch=%d (3 + 6*multires, multires <= 10)", a.input_ch);
+        return NERF_E_INVALID;
+    }
+    if (a.input_ch_views < 3 || a.input_ch_views > 27 || (a.input_ch_views - 3) % 6 != 0) {
+        set_error("unsupported input_ch_views=%d (3 + 6*multires_views, multires_views <= 4)", a.input_ch_views);
+        return NERF_E_INVALID;
+    }
+    if (a.n_skips < 0 || a.n_skips > NERF_MAX_SKIPS) {
+        set_error("n_skips=%d out of range", a.n_skips);
+        return NERF_E_INVALID;
+    }
+    if (!a.use_viewdirs && (a.output_ch < 1 || a.output_ch > 32)) {
+        set_error("unsupported output_ch=%d (1..32)", a.output_ch);
+        return NERF_E_INVALID;
+    }
+    const int want = nerf_num_weight_tensors(&a);
+    if (n_tensors != want) {
+        set_error("expected %d state_dict tensors for this architecture, got %d", want, n_tensors);
+        return NERF_E_INVALID;
+    }
+    for (int i = 0; i < n_tensors; ++i)
+        if (!tensors[i]) {
+            set_error("state_dict tensor %d is NULL", i);
+            return NERF_E_INVALID;
+        }
+
+    uint32_t mask = 0;   // bit i: layer i's input is cat[input_pts, h] (nerf/nerf.py:79-80)
+    for (int k = 0; k < a.n_skips; ++k) {
+        const int s = a.skips[k];
+        if (s < 0 || s >= a.D) continue;   // `i in self.skips` never true: ignored by the reference too
+        if (s == a.D - 1) {
+            // the reference would feed a (W+input_ch)-wide h to its W-wide heads and raise
+            set_error("skip at the last trunk layer (%d) is not a valid reference configuration", s);
+            return NERF_E_INVALID;
+        }
+        mask |= 1u << (s + 1);
+    }
+
+    Stream st;
+    std::vector<float> bias;
+    // gamma(xyz) columns >= input_ch (multires < 10) do not exist; in a skip layer they would
+    // alias the hidden columns that follow input_pts, so bound them here.
+    auto xyz_col = [&](int tile) {
+        const int nx = a.input_ch;
+        return [tile, nx](int t, int h) {
+            const int c = pe_col_xyz(16 * tile + t, h);
+            return (c >= 0 && c < nx) ? c : -1;
+        };
+    };
+
+    for (int i = 0; i < a.D; ++i) {
+        const bool pe_in = (i == 0) || (mask >> i & 1);
+        const int in = (i == 0) ? a.input_ch : (pe_in ? a.W + a.input_ch : a.W);
+        Linear L{tensors[2 * i], tensors[2 * i + 1], a.W, in};
+        bias_tiles(bias, L, 8);
+        if (pe_in) {
+            chunk_ktile(st, L, 8, xyz_col(0));
+            chunk_ktile(st, L, 8, xyz_col(1));
+        }
+        if (i > 0) {
+            const int off = pe_in ? a.input_ch : 0;
+            for (int kt = 0; kt < 8; ++kt)
+                chunk_ktile(st, L, 8, [kt, off](int t, int h) { return off + hidden_col(kt, t, h); });
+        }
+    }
+    // views_linears.0 is tensors[2D], [2D+1] in both variants (nerf/nerf.py:43 builds it always)
+    const float* const* head = tensors + 2 * a.D + 2;
+    if (a.use_viewdirs) {
+        Linear views{tensors[2 * a.D], tensors[2 * a.D + 1], a.W / 2, a.W + a.input_ch_views};
+        Linear feature{head[0], head[1], a.W, a.W};
+        Linear alpha{head[2], head[3], 1, a.W};
+        Linear rgb{head[4], head[5], 3, a.W / 2};
+        // alpha_linear (nerf.py:86): one output tile over all 8 k-tiles: group = kt*4 + t4
+        {
+            float* c = st.new_chunk();
+            for (int kt = 0; kt < 8; ++kt)
+                for (int t4 = 0; t4 < 4; ++t4)
+                    fill_group(c, kt * 4 + t4, alpha, 0, t4, [kt](int t, int h) { return hidden_col(kt, t, h); });
+            bias_tiles(bias, alpha, 1);
+        }
+        // feature_linear (nerf.py:89): a trunk-shaped layer without ReLU
+        bias_tiles(bias, feature, 8);
+        for (int kt = 0; kt < 8; ++kt)
+            chunk_ktile(st, feature, 8, [kt](int t, int h) { return hidden_col(kt, t, h); });
+        // views_linears.0 (nerf.py:93-98): input cat[feature(W), gamma(dir)], 4 output tiles.
+        // two feature k-tiles per chunk: group = (ktl*4 + ot)*4 + t4
+        bias_tiles(bias, views, 4);
+        for (int kp = 0; kp < 4; ++kp) {
+            float* c = st.new_chunk();
+            for (int ktl = 0; ktl < 2; ++ktl)
+                for (int ot = 0; ot < 4; ++ot)
+                    for (int t4 = 0; t4 < 4; ++t4) {
+                        const int kt = 2 * kp + ktl;
+                        fill_group(c, (ktl * 4 + ot) * 4 + t4, views, ot, t4,
+                                   [kt](int t, int h) { return hidden_col(kt, t, h); });
+                    }
+        }
+        {
+            const int off = a.W;
+            const int nv = a.input_ch_views;
+            chunk_ktile(st, views, 4, [off, nv](int t, int h) {
+                const int c = pe_col_dir(t, h);
+                return (c >= 0 && c < nv) ? off + c : -1;
+            });
+        }
+        // rgb_linear (nerf.py:101): one output tile over the 4 k-tiles of the 128-wide view layer
+        {
+            float* c = st.new_chunk();
+            for (int kt = 0; kt < 4; ++kt)
+                for (int t4 = 0; t4 < 4; ++t4)
+                    fill_group(c, kt * 4 + t4, rgb, 0, t4, [kt](int t, int h) { return hidden_col(kt, t, h); });
+            bias_tiles(bias, rgb, 1);
+        }
+        *out_ch = 4;   // cat[rgb, alpha] (nerf.py:106)
+    } else {
+        Linear outl{head[0], head[1], a.output_ch, a.W};
+        float* c = st.new_chunk();
+        for (int kt = 0; kt < 8; ++kt)
+            for (int t4 = 0; t4 < 4; ++t4)
+                fill_group(c, kt * 4 + t4, outl, 0, t4, [kt](int t, int h) { return hidden_col(kt, t, h); });
+        bias_tiles(bias, outl, 1);
+        *out_ch = a.output_ch;
+    }
+    const size_t ns = st.data.size(), nb = bias.size();
+    if (nb * sizeof(float) > (size_t)kBiasLdsBytes) {
+        set_error("bias block of %zu bytes exceeds the %d-byte LDS reservation", nb * sizeof(float), kBiasLdsBytes);
+        return NERF_E_INVALID;
+    }
+    float* s_out = (float*)malloc(ns * sizeof(float));
+    float* b_out = (float*)malloc(nb * sizeof(float));
+    if (!s_out || !b_out) {
+        free(s_out);
+        free(b_out);
+        set_error("out of host memory packing weights");
+        return NERF_E_NOMEM;
+    }
+    memcpy(s_out, st.data.data(), ns * sizeof(float));
+    memcpy(b_out, bias.data(), nb * sizeof(float));
+    *stream_out = s_out;
+    *bias_out = b_out;
+    *n_chunks = (int)(ns / kChunkFloats);
+    *n_bias_tiles = (int)(nb / kBiasTileFloats);
+    *skip_in_mask = mask;
+    return NERF_OK;
+}
+
+}  // namespace nerf

@@ -1,0 +1,650 @@
+"""Host-side mirror of the reference's ray-chunk renderer call surface.
+
+Same names, argument meaning and error behaviour as the notebook cells of
+``nerf/nerf.ipynb`` (``batchify`` :224, ``raw2outputs`` :254, ``render_rays`` :359,
+``batchify_rays`` :514, ``render`` :558, ``run_network`` :790), ``nerf/nerf.py`` (``NeRF``),
+``nerf/embedder.py`` (``get_embedder``) and ``nerf/nerf_helpers.py`` (``sample_pdf``,
+``get_rays``, ``ndc_rays``), but every numeric stage runs in hand-written HIP kernels
+behind the C ABI of ``include/nerf_mi355x.h``. PyTorch is plumbing only: device memory,
+streams, ``torch.distributed``. There is no fallback path: without the built library and a
+gfx950 GPU every entry point raises.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import NerfArch, RenderArgs, check
+
+__all__ = [
+    "NeRF", "get_embedder", "batchify", "run_network", "raw2outputs", "sample_pdf", "render_rays",
+    "batchify_rays", "render", "get_rays", "get_rays_np", "ndc_rays", "make_network_query_fn",
+    "get_context", "img2mse", "mse2psnr", "to8b",
+]
+
+
+# ----------------------------------------------------------------------------------------------
+# context
+# ----------------------------------------------------------------------------------------------
+
+class Context:
+    """One ``nerf_ctx`` per GPU (owns packed weights and the render workspace)."""
+
+    def __init__(self, device_index):
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible to PyTorch: the MI355X renderer has no CPU fallback")
+        self.lib = lib
+        self.device = torch.device("cuda", device_index)
+        handle = C.c_void_p()
+        check(lib.nerf_ctx_create(device_index, C.byref(handle)))
+        self.handle = handle
+        self._slots = [None] * _lib.NERF_NUM_SLOTS
+
+    def alloc_slot(self, owner):
+        for i, o in enumerate(self._slots):
+            if o is None or o() is None:
+                import weakref
+                self._slots[i] = weakref.ref(owner)
+                return i
+        raise RuntimeError(f"all {_lib.NERF_NUM_SLOTS} network slots of the context are in use")
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def profile_enable(self, on=True):
+        check(self.lib.nerf_profile_enable(self.handle, int(bool(on))))
+
+    def profile_read(self, reset=True):
+        """(ms, launches, points) of the fused encode+MLP kernel since the last reset."""
+        ms, n, pts = C.c_double(), C.c_int64(), C.c_int64()
+        check(self.lib.nerf_profile_read(self.handle, C.byref(ms), C.byref(n), C.byref(pts), int(reset)))
+        return ms.value, n.value, pts.value
+
+    def workspace_bytes(self):
+        return int(self.lib.nerf_workspace_bytes(self.handle))
+
+
+_contexts = {}
+
+
+def get_context(device=None):
+    if device is None:
+        if not torch.cuda.is_available():
+            _lib.load()
+            raise RuntimeError("no GPU visible to PyTorch: the MI355X renderer has no CPU fallback")
+        index = torch.cuda.current_device()
+    else:
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(f"device {device} is not a GPU: the MI355X renderer has no CPU fallback")
+        index = device.index if device.index is not None else torch.cuda.current_device()
+    if index not in _contexts:
+        _contexts[index] = Context(index)
+    return _contexts[index]
+
+
+def _dev(t, ctx, dtype=torch.float32):
+    """fp32, contiguous, on the context's GPU (the reference does ``.float().to(model_device)``)."""
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(np.asarray(t))
+    return t.detach().to(device=ctx.device, dtype=dtype).contiguous()
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+# ----------------------------------------------------------------------------------------------
+# NeRF module (nerf/nerf.py:8-146)
+# ----------------------------------------------------------------------------------------------
+
+class NeRF:
+    """Forward-only stand-in for the reference ``NeRF`` ``nn.Module`` (nerf/nerf.py:8-111).
+
+    Same constructor; ``load_state_dict`` accepts the reference's state dict (torch tensors
+    or numpy arrays, keys ``pts_linears.i.weight`` ...) and repacks it for the MFMA kernel.
+    ``__call__(x)`` is ``forward`` on already-encoded rows ``[B, input_ch + input_ch_views]``.
+    """
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False,
+                 device=None):
+        self.D, self.W = int(D), int(W)
+        self.input_ch, self.input_ch_views = int(input_ch), int(input_ch_views)
+        self.output_ch = int(output_ch)
+        self.skips = list(skips)
+        self.use_viewdirs = bool(use_viewdirs)
+        self.ctx = get_context(device)
+        self.slot = self.ctx.alloc_slot(self)
+        self._sd = None
+
+    # -- state dict ------------------------------------------------------------------------
+    def state_dict_keys(self):
+        keys = []
+        for i in range(self.D):
+            keys += [f"pts_linears.{i}.weight", f"pts_linears.{i}.bias"]
+        keys += ["views_linears.0.weight", "views_linears.0.bias"]
+        if self.use_viewdirs:
+            keys += ["feature_linear.weight", "feature_linear.bias", "alpha_linear.weight", "alpha_linear.bias",
+                     "rgb_linear.weight", "rgb_linear.bias"]
+        else:
+            keys += ["output_linear.weight", "output_linear.bias"]
+        return keys
+
+    def _expected_shape(self, key):
+        W, D = self.W, self.D
+        name, kind = key.rsplit(".", 1)
+        if name.startswith("pts_linears"):
+            i = int(name.split(".")[1])
+            fan_in = self.input_ch if i == 0 else (W + self.input_ch if (i - 1) in self.skips else W)
+            shape = (W, fan_in)
+        elif name == "views_linears.0":
+            shape = (W // 2, self.input_ch_views + W)
+        elif name == "feature_linear":
+            shape = (W, W)
+        elif name == "alpha_linear":
+            shape = (1, W)
+        elif name == "rgb_linear":
+            shape = (3, W // 2)
+        else:
+            shape = (self.output_ch, W)
+        return shape if kind == "weight" else shape[:1]
+
+    def load_state_dict(self, state_dict, strict=True):
+        keys = self.state_dict_keys()
+        missing = [k for k in keys if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in keys]
+        if missing or (strict and unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for NeRF: missing {missing}, unexpected {unexpected}")
+        arrays = []
+        for k in keys:
+            v = state_dict[k]
+            v = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+            v = np.ascontiguousarray(v, dtype=np.float32)
+            if tuple(v.shape) != self._expected_shape(k):
+                raise RuntimeError(f"size mismatch for {k}: got {tuple(v.shape)}, expected {self._expected_shape(k)}")
+            arrays.append(v)
+        arch = NerfArch()
+        arch.D, arch.W = self.D, self.W
+        arch.input_ch, arch.input_ch_views, arch.output_ch = self.input_ch, self.input_ch_views, self.output_ch
+        if len(self.skips) > _lib.NERF_MAX_SKIPS:
+            raise RuntimeError(f"at most {_lib.NERF_MAX_SKIPS} skip connections are supported")
+        arch.n_skips = len(self.skips)
+        for i, s in enumerate(self.skips):
+            arch.skips[i] = int(s)
+        arch.use_viewdirs = int(self.use_viewdirs)
+        ptrs = (C.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
+        check(self.ctx.lib.nerf_load_weights(self.ctx.handle, self.slot, C.byref(arch), ptrs, len(arrays)))
+        self._sd = dict(zip(keys, arrays))
+        return self
+
+    def state_dict(self):
+        if self._sd is None:
+            raise RuntimeError("no weights loaded")
+        return {k: torch.from_numpy(v.copy()) for k, v in self._sd.items()}
+
+    def parameters(self):
+        """Yields device placeholders so ``next(fn.parameters()).device`` works (nerf.ipynb:598, :848)."""
+        yield torch.empty(0, device=self.ctx.device)
+
+    @property
+    def device(self):
+        return self.ctx.device
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    @property
+    def out_channels(self):
+        return 4 if self.use_viewdirs else self.output_ch
+
+    # -- forward ---------------------------------------------------------------------------
+    def forward(self, x):
+        if self._sd is None:
+            raise RuntimeError("NeRF.forward before load_state_dict")
+        width = self.input_ch + self.input_ch_views
+        if x.shape[-1] != width:
+            raise RuntimeError(f"split_with_sizes expects the last dimension to be {width}, got {x.shape[-1]}")
+        lead = list(x.shape[:-1])
+        xf = _dev(x, self.ctx).reshape(-1, width)
+        out = torch.empty((xf.shape[0], self.out_channels), device=self.ctx.device, dtype=torch.float32)
+        check(self.ctx.lib.nerf_mlp_forward(self.ctx.handle, self.slot, _ptr(xf), xf.shape[0], _ptr(out),
+                                            self.ctx.stream()))
+        return out.reshape(lead + [self.out_channels])
+
+    __call__ = forward
+
+
+# ----------------------------------------------------------------------------------------------
+# positional encoding (nerf/embedder.py:82-116)
+# ----------------------------------------------------------------------------------------------
+
+class _Embed:
+    """``embed_fn`` returned by :func:`get_embedder`; callable like the reference's lambda."""
+
+    def __init__(self, multires):
+        self.multires = int(multires)
+        self.out_dim = 3 + 6 * self.multires
+
+    def __call__(self, x):
+        ctx = get_context(x.device if torch.is_tensor(x) and x.is_cuda else None)
+        if x.shape[-1] != 3:
+            raise RuntimeError(f"embedder expects 3 input dims, got {x.shape[-1]}")
+        lead = list(x.shape[:-1])
+        xf = _dev(x, ctx).reshape(-1, 3)
+        out = torch.empty((xf.shape[0], self.out_dim), device=ctx.device, dtype=torch.float32)
+        check(ctx.lib.nerf_embed(ctx.handle, _ptr(xf), xf.shape[0], self.multires, _ptr(out), ctx.stream()))
+        return out.reshape(lead + [self.out_dim])
+
+
+def get_embedder(multires, i=0):
+    """``(embed_fn, out_dim)``; ``i == -1`` is the identity with out_dim 3 (embedder.py:89-92)."""
+    if i == -1:
+        e = _Embed(0)
+        return e, 3
+    e = _Embed(multires)
+    return e, e.out_dim
+
+
+# ----------------------------------------------------------------------------------------------
+# batchify / run_network (nerf.ipynb:224-244, 790-855)
+# ----------------------------------------------------------------------------------------------
+
+def batchify(fn, chunk):
+    """nerf.ipynb:224-244."""
+    if chunk is None:
+        return fn
+
+    def ret(inputs):
+        return torch.cat([fn(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
+    return ret
+
+
+def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64):
+    """nerf.ipynb:790-855. With this package's embedders and ``NeRF`` the encoding, the
+    per-sample viewdir broadcast and the MLP run as ONE fused kernel (``netchunk`` only bounded
+    memory in the reference and results do not depend on it); any other ``fn`` /
+    embedder combination is composed stage by stage exactly as the reference does."""
+    fused = (isinstance(fn, NeRF) and isinstance(embed_fn, _Embed)
+             and embed_fn.out_dim == fn.input_ch and inputs.shape[-1] == 3
+             and (viewdirs is None or (isinstance(embeddirs_fn, _Embed)
+                                       and embeddirs_fn.out_dim == fn.input_ch_views)))
+    if fused and (viewdirs is not None) == fn.use_viewdirs:
+        ctx = fn.ctx
+        pts = _dev(inputs, ctx)
+        lead = list(pts.shape[:-1])
+        if viewdirs is not None:
+            n_rays = viewdirs.shape[0]
+            if pts.dim() < 2 or pts.shape[0] != n_rays:
+                raise RuntimeError(f"viewdirs [{n_rays},3] cannot be expanded to inputs {tuple(pts.shape)}")
+            vd = _dev(viewdirs, ctx).reshape(-1, 3)
+        else:
+            n_rays = pts.shape[0] if pts.dim() > 1 else 1
+            vd = None
+        flat = pts.reshape(-1, 3)
+        n_samples = flat.shape[0] // max(n_rays, 1)
+        out = torch.empty((flat.shape[0], fn.out_channels), device=ctx.device, dtype=torch.float32)
+        check(ctx.lib.nerf_run_network(ctx.handle, fn.slot, _ptr(flat), _ptr(vd), n_rays, max(n_samples, 1),
+                                       _ptr(out), ctx.stream()))
+        return out.reshape(lead + [fn.out_channels])
+    # generic composition (nerf.ipynb:827-855)
+    inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+    embedded = embed_fn(inputs_flat)
+    if viewdirs is not None:
+        input_dirs = viewdirs[:, None].expand(inputs.shape)
+        input_dirs_flat = torch.reshape(input_dirs, [-1, input_dirs.shape[-1]])
+        embedded = torch.cat([embedded, embeddirs_fn(input_dirs_flat)], -1)
+    outputs_flat = batchify(fn, netchunk)(embedded)
+    return torch.reshape(outputs_flat, list(inputs.shape[:-1]) + [outputs_flat.shape[-1]])
+
+
+class NetworkQuery:
+    """The ``network_query_fn`` that ``create_nerf`` builds as a lambda (nerf.ipynb:899-902),
+    as an introspectable callable so that ``render_rays`` can take the fully fused path."""
+
+    def __init__(self, embed_fn, embeddirs_fn, netchunk=1024 * 64):
+        self.embed_fn, self.embeddirs_fn, self.netchunk = embed_fn, embeddirs_fn, netchunk
+
+    def __call__(self, inputs, viewdirs, network_fn):
+        return run_network(inputs, viewdirs, network_fn, embed_fn=self.embed_fn,
+                           embeddirs_fn=self.embeddirs_fn, netchunk=self.netchunk)
+
+    def matches(self, net, has_viewdirs):
+        return (isinstance(net, NeRF) and isinstance(self.embed_fn, _Embed)
+                and self.embed_fn.out_dim == net.input_ch and net.use_viewdirs == has_viewdirs
+                and (not has_viewdirs or (isinstance(self.embeddirs_fn, _Embed)
+                                          and self.embeddirs_fn.out_dim == net.input_ch_views)))
+
+
+def make_network_query_fn(embed_fn, embeddirs_fn, netchunk=1024 * 64):
+    return NetworkQuery(embed_fn, embeddirs_fn, netchunk)
+
+
+# ----------------------------------------------------------------------------------------------
+# raw2outputs (nerf.ipynb:254-349)
+# ----------------------------------------------------------------------------------------------
+
+def _noise(shape, raw_noise_std, pytest, ctx):
+    """Sigma noise exactly as the reference draws it (nerf.ipynb:312-325), or None."""
+    try:
+        noise_std = float(raw_noise_std)      # YAML may hand over the string '1e0'
+    except (TypeError, ValueError):
+        noise_std = 0.0
+    if noise_std <= 0.0:
+        return None
+    if pytest:
+        np.random.seed(0)
+        return _dev(np.random.rand(*shape) * noise_std, ctx)
+    return torch.randn(shape, device=ctx.device, dtype=torch.float32) * noise_std
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False):
+    """Returns ``(rgb_map, disp_map, acc_map, weights, depth_map)`` (nerf.ipynb:254-349)."""
+    ctx = get_context(raw.device if torch.is_tensor(raw) and raw.is_cuda else None)
+    raw, z_vals, rays_d = _dev(raw, ctx), _dev(z_vals, ctx), _dev(rays_d, ctx)
+    N, S, Cc = raw.shape
+    if Cc < 4 or tuple(z_vals.shape) != (N, S) or tuple(rays_d.shape) != (N, 3):
+        raise RuntimeError(f"raw2outputs: inconsistent shapes raw {tuple(raw.shape)}, z_vals "
+                           f"{tuple(z_vals.shape)}, rays_d {tuple(rays_d.shape)}")
+    noise = _noise((N, S), raw_noise_std, pytest, ctx)
+    o = dict(device=ctx.device, dtype=torch.float32)
+    rgb, disp, acc = torch.empty((N, 3), **o), torch.empty((N,), **o), torch.empty((N,), **o)
+    weights, depth = torch.empty((N, S), **o), torch.empty((N,), **o)
+    check(ctx.lib.nerf_raw2outputs(ctx.handle, _ptr(raw), Cc, _ptr(z_vals), _ptr(rays_d), _ptr(noise),
+                                   int(bool(white_bkgd)), N, S, _ptr(rgb), _ptr(disp), _ptr(acc), _ptr(weights),
+                                   _ptr(depth), ctx.stream()))
+    return rgb, disp, acc, weights, depth
+
+
+# ----------------------------------------------------------------------------------------------
+# sample_pdf (nerf/nerf_helpers.py:372-439)
+# ----------------------------------------------------------------------------------------------
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
+    ctx = get_context(bins.device if torch.is_tensor(bins) and bins.is_cuda else None)
+    bins, weights = _dev(bins, ctx), _dev(weights, ctx)
+    lead = list(bins.shape[:-1])
+    M = bins.shape[-1]
+    if weights.shape[-1] != M - 1 or list(weights.shape[:-1]) != lead:
+        raise RuntimeError(f"sample_pdf: bins {tuple(bins.shape)} need weights [..., {M - 1}], got "
+                           f"{tuple(weights.shape)}")
+    b2, w2 = bins.reshape(-1, M), weights.reshape(-1, M - 1)
+    N = b2.shape[0]
+    u = None
+    if pytest:                                   # nerf_helpers.py:410-418
+        np.random.seed(0)
+        if det:
+            u = _dev(np.broadcast_to(np.linspace(0.0, 1.0, N_samples), (N, N_samples)).copy(), ctx)
+        else:
+            u = _dev(np.random.rand(*(lead + [N_samples])).reshape(N, N_samples), ctx)
+    elif not det:
+        u = torch.rand((N, N_samples), device=ctx.device, dtype=torch.float32)
+    out = torch.empty((N, N_samples), device=ctx.device, dtype=torch.float32)
+    check(ctx.lib.nerf_sample_pdf(ctx.handle, _ptr(b2), _ptr(w2), _ptr(u), N, M, int(N_samples), _ptr(out),
+                                  ctx.stream()))
+    return out.reshape(lead + [N_samples])
+
+
+# ----------------------------------------------------------------------------------------------
+# render_rays (nerf.ipynb:359-492)
+# ----------------------------------------------------------------------------------------------
+
+def _render_rays_fused(ctx, ray_batch, net_c, net_f, N_samples, N_importance, retraw, lindisp, perturb,
+                       white_bkgd, raw_noise_std, pytest, extras=None, z_vals_fine_in=None):
+    N, stride = ray_batch.shape
+    Sc, Si = int(N_samples), int(N_importance)
+    o = dict(device=ctx.device, dtype=torch.float32)
+    a = RenderArgs()
+    a.rays, a.n_rays, a.ray_stride = ray_batch.data_ptr(), N, stride
+    a.N_samples, a.N_importance = Sc, Si
+    a.slot_coarse = net_c.slot
+    a.slot_fine = net_f.slot if net_f is not None else -1
+    a.lindisp, a.white_bkgd = int(bool(lindisp)), int(bool(white_bkgd))
+    keep = []
+    if perturb > 0.:
+        a.perturb = 1
+        if pytest:                               # nerf.ipynb:439-442: np.random.seed(0) before each draw
+            np.random.seed(0)
+            t_rand = _dev(np.random.rand(N, Sc), ctx)
+        else:
+            t_rand = torch.rand((N, Sc), **o)
+        keep.append(t_rand)
+        a.t_rand = t_rand.data_ptr()
+    n0 = _noise((N, Sc), raw_noise_std, pytest, ctx)
+    if n0 is not None:
+        keep.append(n0)
+        a.noise0 = n0.data_ptr()
+    if Si > 0:
+        if perturb > 0.:
+            if pytest:
+                np.random.seed(0)
+                u = _dev(np.random.rand(N, Si), ctx)
+            else:
+                u = torch.rand((N, Si), **o)
+            keep.append(u)
+            a.u_rand = u.data_ptr()
+        n1 = _noise((N, Sc + Si), raw_noise_std, pytest, ctx)
+        if n1 is not None:
+            keep.append(n1)
+            a.noise = n1.data_ptr()
+    ret = {"rgb_map": torch.empty((N, 3), **o), "disp_map": torch.empty((N,), **o),
+           "acc_map": torch.empty((N,), **o)}
+    a.rgb_map, a.disp_map, a.acc_map = (ret[k].data_ptr() for k in ("rgb_map", "disp_map", "acc_map"))
+    if retraw:
+        last = net_f if (Si > 0 and net_f is not None) else net_c
+        ret["raw"] = torch.empty((N, Sc + Si, last.out_channels), **o)
+        a.raw = ret["raw"].data_ptr()
+    if Si > 0:
+        ret["rgb0"], ret["disp0"], ret["acc0"] = torch.empty((N, 3), **o), torch.empty((N,), **o), torch.empty((N,), **o)
+        ret["z_std"] = torch.empty((N,), **o)
+        a.rgb0, a.disp0, a.acc0, a.z_std = (ret[k].data_ptr() for k in ("rgb0", "disp0", "acc0", "z_std"))
+    if extras is not None:
+        extras["z_coarse"] = torch.empty((N, Sc), **o)
+        extras["weights_coarse"] = torch.empty((N, Sc), **o)
+        a.z_vals_coarse, a.weights_coarse = extras["z_coarse"].data_ptr(), extras["weights_coarse"].data_ptr()
+        if Si > 0:
+            extras["z_samples"] = torch.empty((N, Si), **o)
+            extras["z_fine"] = torch.empty((N, Sc + Si), **o)
+            extras["weights_fine"] = torch.empty((N, Sc + Si), **o)
+            a.z_samples, a.z_vals_fine = extras["z_samples"].data_ptr(), extras["z_fine"].data_ptr()
+            a.weights_fine = extras["weights_fine"].data_ptr()
+    if z_vals_fine_in is not None:
+        zin = _dev(z_vals_fine_in, ctx)
+        keep.append(zin)
+        a.z_vals_fine_in = zin.data_ptr()
+    a.stream = ctx.stream().value
+    check(ctx.lib.nerf_render_rays(ctx.handle, C.byref(a)))
+    # `keep` tensors are consumed by work already enqueued on the current stream; PyTorch's
+    # caching allocator only reuses their memory for later work on that same stream.
+    return ret
+
+
+def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
+                N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False,
+                pytest=False, _extras=None, _z_vals_fine=None):
+    """Volume-render one chunk of rays; same arguments and return dict as nerf.ipynb:359-492.
+
+    When ``network_query_fn`` is this package's :class:`NetworkQuery` over this package's
+    embedders and ``NeRF`` models, the whole chunk (sampling, encoding, both MLP passes,
+    compositing, resampling) runs inside one C call with no host synchronisation. Any other
+    ``network_query_fn`` is honoured as an opaque callable and the stages are composed
+    around it as in the reference, each stage still a HIP kernel.
+    """
+    if not isinstance(network_fn, NeRF):
+        raise TypeError("render_rays needs this package's NeRF for network_fn (no PyTorch fallback exists)")
+    ctx = network_fn.ctx
+    ray_batch = _dev(ray_batch, ctx)
+    if ray_batch.dim() != 2 or ray_batch.shape[-1] not in (8, 11):
+        raise RuntimeError(f"ray_batch must be [N, 8|11], got {tuple(ray_batch.shape)}")
+    has_dirs = ray_batch.shape[-1] > 8
+    perturb = float(perturb)
+    fused = (isinstance(network_query_fn, NetworkQuery) and network_query_fn.matches(network_fn, has_dirs)
+             and (network_fine is None or network_query_fn.matches(network_fine, has_dirs)))
+    if fused:
+        return _render_rays_fused(ctx, ray_batch, network_fn, network_fine, N_samples, N_importance, retraw,
+                                  lindisp, perturb, white_bkgd, raw_noise_std, pytest, _extras, _z_vals_fine)
+
+    # ---- staged composition around an opaque network_query_fn -------------------------------
+    N_rays = ray_batch.shape[0]
+    rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
+    viewdirs = ray_batch[:, -3:] if has_dirs else None
+    near, far = ray_batch[:, 6:7], ray_batch[:, 7:8]
+    t_vals = torch.linspace(0., 1., steps=N_samples, device=ctx.device)
+    if not lindisp:
+        z_vals = near * (1. - t_vals) + far * t_vals
+    else:
+        z_vals = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
+    z_vals = z_vals.expand([N_rays, N_samples])
+    if perturb > 0.:
+        mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+        upper = torch.cat([mids, z_vals[..., -1:]], -1)
+        lower = torch.cat([z_vals[..., :1], mids], -1)
+        if pytest:
+            np.random.seed(0)
+            t_rand = _dev(np.random.rand(*list(z_vals.shape)), ctx)
+        else:
+            t_rand = torch.rand(z_vals.shape, device=ctx.device)
+        z_vals = lower + (upper - lower) * t_rand
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+    raw = network_query_fn(pts, viewdirs, network_fn)
+    rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, raw_noise_std, white_bkgd,
+                                                                 pytest=pytest)
+    if _extras is not None:
+        _extras.update(z_coarse=z_vals, weights_coarse=weights)
+    if N_importance > 0:
+        rgb_map_0, disp_map_0, acc_map_0 = rgb_map, disp_map, acc_map
+        z_vals_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+        z_samples = sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance, det=(perturb == 0.), pytest=pytest)
+        z_vals, _ = torch.sort(torch.cat([z_vals, z_samples], -1), -1)
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+        run_fn = network_fn if network_fine is None else network_fine
+        raw = network_query_fn(pts, viewdirs, run_fn)
+        rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, raw_noise_std,
+                                                                     white_bkgd, pytest=pytest)
+        if _extras is not None:
+            _extras.update(z_samples=z_samples, z_fine=z_vals, weights_fine=weights)
+    ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map}
+    if retraw:
+        ret['raw'] = raw
+    if N_importance > 0:
+        ret['rgb0'], ret['disp0'], ret['acc0'] = rgb_map_0, disp_map_0, acc_map_0
+        ret['z_std'] = torch.std(z_samples, dim=-1, unbiased=False)
+    return ret
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
+    """nerf.ipynb:514-548."""
+    all_ret = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        ret = render_rays(rays_flat[i:i + chunk], **kwargs)
+        for k in ret:
+            all_ret.setdefault(k, []).append(ret[k])
+    return {k: torch.cat(all_ret[k], dim=0) for k in all_ret}
+
+
+# ----------------------------------------------------------------------------------------------
+# ray generation and render() (nerf_helpers.py:222-369, nerf.ipynb:558-640)
+# ----------------------------------------------------------------------------------------------
+
+def get_rays(H, W, K, c2w):
+    """nerf_helpers.py:222-296 (torch ops on ``c2w``'s device; ray generation is a caller of the
+    hot path)."""
+    device, dtype = c2w.device, c2w.dtype
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W, device=device, dtype=dtype),
+                          torch.linspace(0, H - 1, H, device=device, dtype=dtype), indexing="ij")
+    i, j = i.t(), j.t()
+    dirs = torch.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -torch.ones_like(i)], dim=-1)
+    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], dim=-1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def get_rays_np(H, W, K, c2w):
+    """nerf_helpers.py:301-308."""
+    i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing='xy')
+    dirs = np.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -np.ones_like(i)], -1)
+    rays_d = np.sum(dirs[..., np.newaxis, :] * c2w[:3, :3], -1)
+    rays_o = np.broadcast_to(c2w[:3, -1], np.shape(rays_d))
+    return rays_o, rays_d
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """nerf_helpers.py:311-369."""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    o0 = -1. / (W / (2. * focal)) * rays_o[..., 0] / rays_o[..., 2]
+    o1 = -1. / (H / (2. * focal)) * rays_o[..., 1] / rays_o[..., 2]
+    o2 = 1. + 2. * near / rays_o[..., 2]
+    d0 = -1. / (W / (2. * focal)) * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
+    d1 = -1. / (H / (2. * focal)) * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
+    d2 = -2. * near / rays_o[..., 2]
+    return torch.stack([o0, o1, o2], dim=-1), torch.stack([d0, d1, d2], dim=-1)
+
+
+def pack_rays(H, W, K, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+              c2w_staticcam=None, device=None):
+    """The ``[N, 8|11]`` ray record ``render()`` builds (nerf.ipynb:596-629) and the grid shape."""
+    if c2w is not None:
+        if not torch.is_tensor(c2w):
+            c2w = torch.as_tensor(np.asarray(c2w), dtype=torch.float32)
+        if device is not None:
+            c2w = c2w.to(device)
+        rays_o, rays_d = get_rays(H, W, K, c2w)
+    else:
+        rays_o, rays_d = rays
+        if not torch.is_tensor(rays_o):
+            rays_o, rays_d = torch.as_tensor(np.asarray(rays_o)), torch.as_tensor(np.asarray(rays_d))
+        if device is not None:
+            rays_o, rays_d = rays_o.to(device), rays_d.to(device)
+    viewdirs = None
+    if use_viewdirs:
+        viewdirs = rays_d
+        if c2w_staticcam is not None:
+            if not torch.is_tensor(c2w_staticcam):
+                c2w_staticcam = torch.as_tensor(np.asarray(c2w_staticcam), dtype=torch.float32)
+            rays_o, rays_d = get_rays(H, W, K, c2w_staticcam.to(rays_d.device))
+        viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
+        viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+    sh = rays_d.shape
+    if ndc:
+        rays_o, rays_d = ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
+    rays_o = torch.reshape(rays_o, [-1, 3]).float()
+    rays_d = torch.reshape(rays_d, [-1, 3]).float()
+    near_c, far_c = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
+    packed = torch.cat([rays_o, rays_d, near_c, far_c], -1)
+    if use_viewdirs:
+        packed = torch.cat([packed, viewdirs], -1)
+    return packed, sh
+
+
+def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+           c2w_staticcam=None, **kwargs):
+    """``[rgb_map, disp_map, acc_map, extras]`` reshaped to the ray grid (nerf.ipynb:558-640)."""
+    model_device = next(kwargs['network_fn'].parameters()).device
+    packed, sh = pack_rays(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, device=model_device)
+    all_ret = batchify_rays(packed, chunk, **kwargs)
+    for k in all_ret:
+        all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
+    k_extract = ['rgb_map', 'disp_map', 'acc_map']
+    return [all_ret[k] for k in k_extract] + [{k: all_ret[k] for k in all_ret if k not in k_extract}]
+
+
+# ----------------------------------------------------------------------------------------------
+# metrics used by the PSNR report (nerf_helpers.py:8-18)
+# ----------------------------------------------------------------------------------------------
+
+def img2mse(x, y):
+    return torch.mean((x - y) ** 2)
+
+
+def mse2psnr(x):
+    return -10.0 * torch.log(x) / math.log(10.0)
+
+
+def to8b(x):
+    return (255 * np.clip(x, 0, 1)).astype(np.uint8)

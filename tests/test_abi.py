@@ -1,0 +1,89 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/nerf_mi355x.h declares, the ctypes structs match the header, and the product path fails
+loudly (never falls back) when no GPU is present. No compute calls are made here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "nerf_mi355x.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nerf_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from nerf_projects_amd import _lib
+    if not os.path.exists(_lib.library_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    from nerf_projects_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/nerf_mi355x.h but not exported"
+    assert sorted(_lib.EXPORTS) == names, "ctypes binding and header disagree on the entry points"
+
+
+def test_struct_layout_matches_header(lib, tmp_path):
+    """sizeof/offsetof from a C compile of the header vs the ctypes mirror."""
+    from nerf_projects_amd import _lib
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nerf_mi355x.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %d\\n", sizeof(nerf_arch), '
+                   'sizeof(nerf_render_args), offsetof(nerf_render_args, rgb_map), '
+                   'offsetof(nerf_render_args, z_vals_fine_in), offsetof(nerf_render_args, stream), '
+                   'offsetof(nerf_arch, use_viewdirs), NERF_NUM_SLOTS);return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    A, R = _lib.NerfArch, _lib.RenderArgs
+    want = [ctypes.sizeof(A), ctypes.sizeof(R), R.rgb_map.offset, R.z_vals_fine_in.offset, R.stream.offset,
+            A.use_viewdirs.offset, _lib.NERF_NUM_SLOTS]
+    assert got == want
+
+
+def test_version_and_tensor_count(lib):
+    from nerf_projects_amd import _lib
+    assert b"gfx950" in lib.nerf_version()
+    a = _lib.NerfArch()
+    a.D, a.W, a.use_viewdirs = 8, 256, 1
+    assert lib.nerf_num_weight_tensors(ctypes.byref(a)) == 24
+    a.use_viewdirs = 0
+    assert lib.nerf_num_weight_tensors(ctypes.byref(a)) == 20
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_fails_loudly(lib):
+    import nerf_projects_amd as N
+    with pytest.raises(RuntimeError, match="no CPU fallback|no GPU"):
+        N.get_context()
+    with pytest.raises(RuntimeError):
+        N.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, use_viewdirs=True)
+    handle = ctypes.c_void_p()
+    assert lib.nerf_ctx_create(0, ctypes.byref(handle)) != 0
+    assert len(lib.nerf_last_error()) > 0
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure; nothing under the package may reference it."""
+    pkg = os.path.join(ROOT, "nerf-projects_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "build" in dirpath.split(os.sep):
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "nerf_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f

@@ -1,0 +1,321 @@
+"""Parity of the HIP path (through the C ABI) with the reference-generated golden fixtures and
+with the CPU oracle. Needs a real MI355X: run with ``pytest -m gpu``.
+
+Tolerances are fp32 stage tolerances and are written at each check;
+sample_pdf and the end-to-end fine render use the conditioning-aware checks of conftest.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import check_end_to_end, check_sample_pdf, load_golden
+from nerf_projects_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def N():
+    import nerf_projects_amd as pkg
+    pkg.get_context()        # raises loudly if the HIP library or the GPU is missing
+    return pkg
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import nerf_oracle
+    return nerf_oracle
+
+
+def gpu(x):
+    return torch.as_tensor(np.ascontiguousarray(x)).cuda()
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def make_net(N, sd, **arch):
+    kw = dict(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True)
+    kw.update(arch)
+    return N.NeRF(**kw).load_state_dict(sd)
+
+
+@pytest.fixture(scope="module")
+def nets(N, weights_pair):
+    sd_c, sd_f = weights_pair
+    net_c, net_f = make_net(N, sd_c), make_net(N, sd_f)
+    q = N.make_network_query_fn(N.get_embedder(10, 0)[0], N.get_embedder(4, 0)[0])
+    return net_c, net_f, q
+
+
+# ---- stage kernels ---------------------------------------------------------------------------
+
+def test_native_library_is_loaded(N):
+    import os
+    from nerf_projects_amd import _lib
+    with open(f"/proc/{os.getpid()}/maps") as f:
+        assert "libnerf_mi355x.so" in f.read()
+    assert b"gfx950" in _lib.load().nerf_version()
+
+
+def test_embed(N):
+    g = load_golden("embed")
+    e, dim = N.get_embedder(10, 0)
+    ed, ddim = N.get_embedder(4, 0)
+    assert (dim, ddim) == (63, 27)
+    # sin/cos of arguments up to 4.5*512 rad: both sides are <= ~1.5 ulp from the true value
+    np.testing.assert_allclose(cpu(e(gpu(g["x"]))), g["gamma_x"], rtol=0, atol=5e-7)
+    np.testing.assert_allclose(cpu(ed(gpu(g["d"]))), g["gamma_d"], rtol=0, atol=5e-7)
+    ident, idim = N.get_embedder(10, -1)
+    assert idim == 3 and np.array_equal(cpu(ident(gpu(g["x"]))), g["identity"])
+    # leading dims are preserved like the reference's lambda
+    assert e(gpu(g["x"]).reshape(8, 8, 3)).shape == (8, 8, 63)
+
+
+def test_mlp_forward(N):
+    g = load_golden("mlp_forward")
+    x = gpu(g["embedded"])
+    out = cpu(make_net(N, synthetic.synthetic_state_dict(7))(x))
+    scale = max(1.0, np.abs(g["out"]).max())
+    assert np.abs(out - g["out"]).max() <= 3e-6 * scale            # vs reference fp32
+    floor = np.abs(g["out"] - g["out_fp64"]).max()
+    assert np.abs(out - g["out_fp64"]).max() <= 4 * floor + 1e-6   # vs reference fp64
+    out5 = cpu(make_net(N, synthetic.synthetic_state_dict(8, use_viewdirs=False, output_ch=5),
+                        use_viewdirs=False, output_ch=5)(x))
+    assert out5.shape == (256, 5)
+    assert np.abs(out5 - g["out_noview5"]).max() <= 3e-6 * max(1.0, np.abs(g["out_noview5"]).max())
+    out4 = cpu(make_net(N, synthetic.synthetic_state_dict(9, D=4, skips=(1,)), D=4, skips=[1])(x))
+    assert np.abs(out4 - g["out_d4"]).max() <= 3e-6 * max(1.0, np.abs(g["out_d4"]).max())
+    # ragged batch (not a multiple of the 128-point workgroup tile) and batch of one
+    net = make_net(N, synthetic.synthetic_state_dict(7))
+    assert np.abs(cpu(net(x[:77])) - g["out"][:77]).max() <= 3e-6 * scale
+    assert np.abs(cpu(net(x[5:6])) - g["out"][5:6]).max() <= 3e-6 * scale
+    assert net(x[:0]).shape == (0, 4)
+
+
+def test_run_network_fused_matches_staged(N, O):
+    """Fused encode+MLP == embed kernel -> cat -> MLP kernel, and both == oracle."""
+    g = load_golden("mlp_forward")
+    sd = synthetic.synthetic_state_dict(7)
+    net = make_net(N, sd)
+    e, _ = N.get_embedder(10, 0)
+    ed, _ = N.get_embedder(4, 0)
+    pts = gpu(g["pts"]).reshape(32, 8, 3)
+    dirs = gpu(g["dirs"][:32])
+    fused = cpu(N.run_network(pts, dirs, net, e, ed))
+    assert fused.shape == (32, 8, 4)
+    staged = cpu(N.run_network(pts, dirs, lambda x: net(x), e, ed, netchunk=100))   # opaque fn: generic path
+    onet = O.NeRF(8, 256, 63, 27, 4, (4,), True, sd)
+    want = O.run_network(g["pts"].reshape(32, 8, 3), g["dirs"][:32], onet, O.get_embedder(10)[0], O.get_embedder(4)[0])
+    scale = max(1.0, np.abs(want).max())
+    assert np.abs(fused - want).max() <= 5e-6 * scale
+    assert np.abs(staged - want).max() <= 5e-6 * scale
+
+
+NAMES = ("rgb_map", "disp_map", "acc_map", "weights", "depth_map")
+
+
+def _close(a, b, atol=2e-6, rtol=5e-6):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_raw2outputs(N):
+    g = load_golden("raw2outputs")
+    raw, z, d = gpu(g["raw"]), gpu(g["z_vals"]), gpu(g["rays_d"])
+    for wb in (0, 1):
+        out = N.raw2outputs(raw, z, d, 0, bool(wb))
+        for name, o in zip(NAMES, out):
+            _close(cpu(o), g[f"{name}_wb{wb}"])
+    out = N.raw2outputs(raw, z, d, raw_noise_std='1e0', white_bkgd=True, pytest=True)
+    for name, o in zip(NAMES, out):
+        _close(cpu(o), g[f"{name}_noise"])
+    _close(cpu(N.raw2outputs(gpu(g["raw5"]), z, d, 0, True)[0]), g["rgb_map_raw5"])
+    for tag, raw_k, z_k, nr in (("s8", "raw8", "z8", 4), ("s192", "raw192", "z192", 8)):
+        out = N.raw2outputs(gpu(g[raw_k]), gpu(g[z_k]), d[:nr], 0, True)
+        for name, o in zip(NAMES, out):
+            _close(cpu(o), g[f"{name}_{tag}"], atol=5e-6)
+
+
+def test_sample_pdf(N, O):
+    g = load_golden("sample_pdf")
+    bins, w = g["bins"], g["weights"]
+    u128 = np.broadcast_to(O.linspace_f32(0, 1, 128), (32, 128))
+    u64 = np.broadcast_to(O.linspace_f32(0, 1, 64), (32, 64))
+    check_sample_pdf(cpu(N.sample_pdf(gpu(bins), gpu(w), 128, det=True)), g["det128"], bins, w, u128)
+    check_sample_pdf(cpu(N.sample_pdf(gpu(bins), gpu(w), 64, det=True)), g["det64"], bins, w, u64)
+    check_sample_pdf(cpu(N.sample_pdf(gpu(bins), gpu(w), 128, det=False, pytest=True)), g["rnd128"], bins, w,
+                     g["u_rnd"])
+    _close(cpu(N.sample_pdf(gpu(g["bins7"]), gpu(g["weights7"]), 16, det=True)), g["det7_16"], atol=3e-6)
+    det = cpu(N.sample_pdf(gpu(bins), gpu(w), 128, det=True))
+    assert np.all(np.diff(det, axis=-1) >= 0) and np.all(det[:, -1] <= bins[:, -1])
+
+
+# ---- render_rays -----------------------------------------------------------------------------
+
+def test_render_rays_c0(N, nets):
+    g = load_golden("render_rays_c0")
+    net_c, _, q = nets
+    ex = {}
+    ret = N.render_rays(gpu(g["rays"]), net_c, q, N_samples=8, retraw=True, white_bkgd=True, _extras=ex)
+    assert set(ret) == {"rgb_map", "disp_map", "acc_map", "raw"}
+    assert np.array_equal(cpu(ex["z_coarse"]), g["z_coarse"])           # stratified depths: bit exact
+    _close(cpu(ret["raw"]), g["raw"], atol=3e-5, rtol=1e-5)
+    for k in ("rgb_map", "disp_map", "acc_map"):
+        _close(cpu(ret[k]), g[k], atol=3e-6)
+
+
+def test_render_rays_lego_stagewise(N, nets):
+    """Every stage fed the reference's own intermediates."""
+    g = load_golden("render_rays_lego")
+    net_c, net_f, q = nets
+    rays = gpu(g["rays"])
+    ex = {}
+    ret = N.render_rays(rays, net_c, q, N_samples=64, N_importance=128, network_fine=net_f, white_bkgd=True,
+                        retraw=True, _extras=ex, _z_vals_fine=g["z_fine"])
+    assert np.array_equal(cpu(ex["z_coarse"]), g["z_coarse"])
+    # coarse pass is well conditioned: plain L-infinity bounds against the reference
+    assert np.abs(cpu(ret["rgb0"]) - g["rgb0"]).max() <= 1e-5
+    assert np.abs(cpu(ret["acc0"]) - g["acc0"]).max() <= 1e-5
+    _close(cpu(ex["weights_coarse"]), g["weights_coarse"], atol=2e-6, rtol=1e-4)
+    # fine network + compositing evaluated at the reference's fine depths: <= 1e-4 per pixel
+    sig = max(1.0, np.abs(g["raw"]).max())
+    assert np.abs(cpu(ret["raw"]) - g["raw"]).max() <= 5e-6 * sig
+    assert np.abs(cpu(ret["rgb_map"]) - g["rgb_map"]).max() <= 2e-5
+    assert np.abs(cpu(ret["acc_map"]) - g["acc_map"]).max() <= 2e-5
+    _close(cpu(ret["disp_map"]), g["disp_map"], atol=1e-5, rtol=1e-4)
+    # hierarchical sampling on the reference's coarse weights
+    mids = np.float32(.5) * (g["z_coarse"][:, 1:] + g["z_coarse"][:, :-1])
+    zs = cpu(N.sample_pdf(gpu(mids), gpu(g["weights_coarse"][:, 1:-1]), 128, det=True))
+    from oracle import nerf_oracle as O
+    u = np.broadcast_to(O.linspace_f32(0, 1, 128), zs.shape)
+    assert check_sample_pdf(zs, g["z_samples"], mids, g["weights_coarse"][:, 1:-1], u) < 0.05
+    # merge: the pipeline's own z_fine is the sorted union of its coarse depths and samples
+    merged = np.sort(np.concatenate([cpu(ex["z_coarse"]), cpu(ex["z_samples"])], -1), -1)
+    assert np.array_equal(cpu(ex["z_fine"]), merged)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("render_rays_lego", dict(N_samples=64, N_importance=128, white_bkgd=True)),
+    ("render_rays_ndc", dict(N_samples=64, N_importance=128, white_bkgd=False)),
+])
+def test_render_rays_end_to_end(N, nets, name, kw):
+    g = load_golden(name)
+    net_c, net_f, q = nets
+    ret = N.render_rays(gpu(g["rays"]), net_c, q, network_fine=net_f, perturb=0., raw_noise_std=0., **kw)
+    assert set(ret) == {"rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"}
+    for k in ("rgb0", "acc0"):
+        assert np.abs(cpu(ret[k]) - g[k]).max() <= 1e-5, k
+    check_end_to_end(cpu(ret["rgb_map"]), g["rgb_map"], g["rgb_map_fp64"])
+    assert np.median(np.abs(cpu(ret["z_std"]) - g["z_std"])) <= 1e-5
+
+
+def test_render_rays_variants(N, nets):
+    net_c, net_f, q = nets
+    g = load_golden("render_rays_lindisp")
+    ret = N.render_rays(gpu(g["rays"]), net_c, q, N_samples=64, N_importance=64, lindisp=True, white_bkgd=False,
+                        network_fine=None)
+    for k in ("rgb0", "acc0", "disp0"):
+        _close(cpu(ret[k]), g[k], atol=1e-5, rtol=1e-4)
+    check_end_to_end(cpu(ret["rgb_map"]), g["rgb_map"])
+    g = load_golden("render_rays_perturb")
+    ex = {}
+    ret = N.render_rays(gpu(g["rays"]), net_c, q, N_samples=64, N_importance=128, white_bkgd=True,
+                        network_fine=net_f, perturb=1.0, raw_noise_std=1.0, pytest=True, _extras=ex)
+    _close(cpu(ex["z_coarse"]), g["z_coarse"], atol=1e-6)
+    for k in ("rgb0", "acc0"):
+        assert np.abs(cpu(ret[k]) - g[k]).max() <= 2e-5, k
+    check_end_to_end(cpu(ret["rgb_map"]), g["rgb_map"])
+
+
+def test_fused_equals_staged(N, nets):
+    """The single-call pipeline and the composition around an opaque network_query_fn agree."""
+    g = load_golden("render_rays_lego")
+    net_c, net_f, q = nets
+    rays = gpu(g["rays"][:96])
+    kw = dict(N_samples=64, N_importance=128, network_fine=net_f, white_bkgd=True, retraw=True)
+    a = N.render_rays(rays, net_c, q, **kw)
+    b = N.render_rays(rays, net_c, lambda i, v, f: q(i, v, f), **kw)
+    assert set(a) == set(b)
+    for k in ("rgb0", "acc0", "disp0"):
+        assert np.abs(cpu(a[k]) - cpu(b[k])).max() <= 2e-6, k
+    check_end_to_end(cpu(a["rgb_map"]), cpu(b["rgb_map"]))
+
+
+def test_render_small_frame(N, nets):
+    g = load_golden("render_small")
+    net_c, net_f, q = nets
+    H, W = int(g["H"]), int(g["W"])
+    kw = dict(network_fn=net_c, network_fine=net_f, network_query_fn=q, N_samples=16, N_importance=16,
+              white_bkgd=True)
+    rgb, disp, acc, extras = N.render(H, W, g["K"], chunk=50, c2w=torch.from_numpy(g["c2w"]), ndc=False,
+                                      near=2., far=6., use_viewdirs=True, **kw)
+    assert rgb.shape == (H, W, 3) and disp.shape == (H, W) and acc.shape == (H, W)
+    assert set(extras) == {"rgb0", "disp0", "acc0", "z_std"}
+    assert np.abs(cpu(extras["rgb0"]) - g["rgb0"]).max() <= 1e-5
+    check_end_to_end(cpu(rgb).reshape(-1, 3), g["rgb"].reshape(-1, 3))
+    # chunk independence: identical bits, any chunking
+    rgb2 = N.render(H, W, g["K"], chunk=7, c2w=torch.from_numpy(g["c2w"]), ndc=False, near=2., far=6.,
+                    use_viewdirs=True, **kw)[0]
+    assert torch.equal(rgb, rgb2)
+    # rays given as a tuple instead of c2w (nerf.ipynb:604-605)
+    ro, rd = N.get_rays(H, W, g["K"], torch.from_numpy(g["c2w"]))
+    rgb3 = N.render(H, W, g["K"], chunk=64, rays=(ro, rd), ndc=False, near=2., far=6., use_viewdirs=True, **kw)[0]
+    assert torch.equal(rgb, rgb3)
+
+
+def test_ray_packing(N):
+    g = load_golden("lego_frame_rays")
+    packed, sh = N.pack_rays(800, 800, g["K"], c2w=g["c2w"], ndc=False, near=2., far=6., use_viewdirs=True,
+                             device="cuda")
+    assert tuple(sh) == (800, 800, 3) and packed.shape == (640000, 11)
+    np.testing.assert_allclose(cpu(packed)[g["pix"]], g["rays"], rtol=0, atol=1e-6)
+
+
+# ---- full-size properties (BASELINE.json configs; no oracle at this size) -------------------------
+
+def test_full_chunk_properties(N, O, nets):
+    """One 32768-ray chunk of the 800x800 lego frame at 64+128: finite, bounded, chunk-independent,
+    and equal to the oracle on a random subset of its rays."""
+    net_c, net_f, q = nets
+    K, c2w, near, far = synthetic.lego_camera(800, 800)
+    packed, _ = N.pack_rays(800, 800, K, c2w=c2w, ndc=False, near=near, far=far, use_viewdirs=True, device="cuda")
+    chunk = packed[300 * 800: 300 * 800 + 32768].contiguous()
+    kw = dict(N_samples=64, N_importance=128, network_fine=net_f, white_bkgd=True)
+    full = N.render_rays(chunk, net_c, q, **kw)
+    rgb = cpu(full["rgb_map"])
+    assert np.isfinite(rgb).all() and rgb.min() >= -1e-5 and rgb.max() <= 1 + 1e-5
+    acc = cpu(full["acc_map"])
+    assert acc.min() >= 0 and acc.max() <= 1 + 1e-5
+    # every ray is independent: a sub-chunk renders to identical bits
+    sub = N.render_rays(chunk[1000:1000 + 4099], net_c, q, **kw)
+    assert torch.equal(sub["rgb_map"], full["rgb_map"][1000:1000 + 4099])
+    # oracle on 64 random rays of the chunk
+    idx = np.sort(np.random.RandomState(1).choice(32768, 64, replace=False))
+    sd_c, sd_f = net_c._sd, net_f._sd
+    oq = O.make_query_fn(O.get_embedder(10)[0], O.get_embedder(4)[0])
+    want = O.render_rays(cpu(chunk)[idx], O.NeRF(8, 256, 63, 27, 4, (4,), True, sd_c), oq, N_samples=64,
+                         N_importance=128, network_fine=O.NeRF(8, 256, 63, 27, 4, (4,), True, sd_f), white_bkgd=True)
+    assert np.abs(cpu(full["rgb0"])[idx] - want["rgb0"]).max() <= 1e-5
+    check_end_to_end(rgb[idx], want["rgb_map"])
+
+
+# ---- error behaviour -------------------------------------------------------------------------
+
+def test_errors_are_exceptions(N, nets):
+    net_c, net_f, q = nets
+    with pytest.raises(RuntimeError):
+        N.NeRF(D=8, W=128, input_ch=63, input_ch_views=27, use_viewdirs=True).load_state_dict(
+            synthetic.synthetic_state_dict(3, W=128))                    # unsupported width: loud, not silent
+    with pytest.raises(RuntimeError):
+        make_net(N, {k: v for k, v in synthetic.synthetic_state_dict(7).items() if "alpha" not in k})
+    with pytest.raises(RuntimeError):
+        net_c(torch.zeros(4, 91).cuda())                                  # wrong encoded width
+    with pytest.raises(RuntimeError):
+        N.render_rays(torch.zeros(4, 9).cuda(), net_c, q, N_samples=8)    # bad ray record
+    with pytest.raises(RuntimeError):
+        N.render_rays(torch.zeros(4, 8).cuda(), net_c, q, N_samples=8)              # viewdirs model, 8 columns
+    with pytest.raises(TypeError):
+        N.render_rays(torch.zeros(4, 11).cuda(), torch.nn.Linear(3, 3), q, N_samples=8)
+    empty = N.render_rays(torch.zeros(0, 11).cuda(), net_c, q, N_samples=8, N_importance=8, network_fine=net_f)
+    assert empty["rgb_map"].shape == (0, 3)

@@ -1,0 +1,91 @@
+"""The N>1 path on CPU: two `gloo` ranks shard a frame's rays, render their shards with an injected
+renderer (the oracle - allowed here, this is tests/) and gather to rank 0. Checks the partition,
+the single gather, padding of uneven shards, and equality with the single-process render."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_partition():
+    from nerf_projects_amd import shard_bounds
+    for n, w in ((640000, 8), (762048, 8), (10, 3), (7, 8), (0, 2), (120, 1)):
+        spans = [shard_bounds(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert shard_bounds(640000, 8, 3) == (240000, 320000)      # 100 image rows per GPU at 800x800
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_chunks(rays, chunk, **kw):
+    from oracle import nerf_oracle as O
+    out = O.batchify_rays(rays.numpy(), chunk, **kw)
+    return {k: torch.from_numpy(v) for k, v in out.items()}
+
+
+def _worker(rank, world, port, H, W, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        import nerf_projects_amd as N
+        from nerf_projects_amd import synthetic
+        from oracle import nerf_oracle as O
+        sd_c, sd_f = synthetic.synthetic_pair(0)
+        net_c = O.NeRF(8, 256, 63, 27, 4, (4,), True, sd_c)
+        oq = O.make_query_fn(O.get_embedder(10)[0], O.get_embedder(4)[0])
+        K = synthetic.intrinsics(H, W, synthetic.blender_focal(W))
+        c2w = synthetic.pose_spherical(30.0, -30.0, 4.0)[:3, :4]
+        out = N.render_sharded(H, W, K, chunk=16, c2w=c2w, ndc=False, near=2., far=6., use_viewdirs=True,
+                               render_chunks=_oracle_chunks, network_fn=net_c, network_query_fn=oq,
+                               N_samples=8, white_bkgd=True)
+        if rank == 0:
+            q.put([o.numpy() if torch.is_tensor(o) else o for o in out[:3]])
+        else:
+            assert out is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H,W", [(6, 8), (5, 7)])          # even and uneven (35 rays over 2 ranks)
+def test_two_rank_gloo_render(H, W):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, H, W, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    rgb, disp, acc = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    from nerf_projects_amd import synthetic
+    from oracle import nerf_oracle as O
+    sd_c, _ = synthetic.synthetic_pair(0)
+    net_c = O.NeRF(8, 256, 63, 27, 4, (4,), True, sd_c)
+    oq = O.make_query_fn(O.get_embedder(10)[0], O.get_embedder(4)[0])
+    K = synthetic.intrinsics(H, W, synthetic.blender_focal(W))
+    c2w = synthetic.pose_spherical(30.0, -30.0, 4.0)[:3, :4]
+    want = O.render(H, W, K, chunk=1000, c2w=c2w, ndc=False, near=2., far=6., use_viewdirs=True,
+                    network_fn=net_c, network_query_fn=oq, N_samples=8, white_bkgd=True)
+    assert rgb.shape == (H, W, 3) and disp.shape == (H, W) and acc.shape == (H, W)
+    np.testing.assert_allclose(rgb, want[0], atol=2e-6)
+    np.testing.assert_allclose(acc, want[2], atol=2e-6)
