@@ -251,6 +251,7 @@ int nerf_load_weights(nerf_ctx* c, int slot, const nerf_arch* arch, const float*
 }
 
 int nerf_embed(nerf_ctx* c, const float* x, int64_t n, int multires, float* out, void* stream) {
+    if (c && n == 0) return NERF_OK;
     if (!c || !x || !out || n < 0 || multires < 0 || multires > 16) {
         set_error("nerf_embed: invalid argument");
         return NERF_E_INVALID;
@@ -261,6 +262,7 @@ int nerf_embed(nerf_ctx* c, const float* x, int64_t n, int multires, float* out,
 }
 
 int nerf_mlp_forward(nerf_ctx* c, int slot, const float* x, int64_t B, float* out, void* stream) {
+    if (c && B == 0) return NERF_OK;
     if (!c || !x || !out || B < 0) {
         set_error("nerf_mlp_forward: invalid argument");
         return NERF_E_INVALID;
@@ -279,6 +281,7 @@ int nerf_mlp_forward(nerf_ctx* c, int slot, const float* x, int64_t B, float* ou
 
 int nerf_run_network(nerf_ctx* c, int slot, const float* pts, const float* viewdirs, int64_t n_rays,
                      int64_t n_samples, float* out, void* stream) {
+    if (c && n_rays == 0) return NERF_OK;
     if (!c || !pts || !out || n_rays < 0 || n_samples <= 0) {
         set_error("nerf_run_network: invalid argument");
         return NERF_E_INVALID;
@@ -302,6 +305,7 @@ int nerf_run_network(nerf_ctx* c, int slot, const float* pts, const float* viewd
 int nerf_raw2outputs(nerf_ctx* c, const float* raw, int C, const float* z_vals, const float* rays_d,
                      const float* noise, int white_bkgd, int64_t N, int S, float* rgb_map, float* disp_map,
                      float* acc_map, float* weights, float* depth_map, void* stream) {
+    if (c && N == 0) return NERF_OK;
     if (!c || !raw || !z_vals || !rays_d || C < 4 || N < 0 || S < 1) {
         set_error("nerf_raw2outputs: invalid argument (C >= 4, S >= 1 required)");
         return NERF_E_INVALID;
@@ -314,6 +318,7 @@ int nerf_raw2outputs(nerf_ctx* c, const float* raw, int C, const float* z_vals, 
 
 int nerf_sample_pdf(nerf_ctx* c, const float* bins, const float* weights, const float* u, int64_t N, int M,
                     int n_samples, float* out, void* stream) {
+    if (c && N == 0) return NERF_OK;
     if (!c || !bins || !weights || !out || N < 0 || M < 2 || n_samples < 1 || M > 4096 || n_samples > 4096) {
         set_error("nerf_sample_pdf: invalid argument (2 <= M <= 4096, 1 <= n_samples <= 4096)");
         return NERF_E_INVALID;
@@ -325,7 +330,7 @@ int nerf_sample_pdf(nerf_ctx* c, const float* bins, const float* weights, const 
 }
 
 int nerf_render_rays(nerf_ctx* c, const nerf_render_args* r) {
-    if (!c || !r || !r->rays || r->n_rays < 0) {
+    if (!c || !r || (!r->rays && r->n_rays != 0) || r->n_rays < 0) {
         set_error("nerf_render_rays: NULL argument");
         return NERF_E_INVALID;
     }
