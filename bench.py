@@ -82,6 +82,18 @@ def cpu_baseline(sample_rays, sd_c, sd_f, Sc, Si, white, target_s):
                               f"{n / dt:.0f} rays/s"}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this
+    same command (profiles/rNN_pmc_summary.json, newest round; FETCH_SIZE doubled as the MI355X guide
+    prescribes for gfx950, WRITE_SIZE as read). bench.py itself cannot read PMC counters."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    s = json.load(open(files[-1]))
+    return s.get("hbm_bytes_per_launch_fetch_x2"), os.path.relpath(files[-1], ROOT)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,6 +175,7 @@ def main():
         flop_per_launch = pts_sum / max(launches_sum, 1) * FLOP_PER_EVAL
         avg_launch_s = mlp_ms_sum / max(launches_sum, 1) * 1e-3
         achieved = flop_per_launch / max(avg_launch_s, 1e-12) / 1e12
+        traffic, traffic_src = pmc_traffic() if args.workload == "lego_800x800_64c+128f" else (None, None)
         out = {
             "metric": "ray_samples_per_sec", "value": value, "unit": "ray-samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -174,7 +187,8 @@ def main():
             "rays_per_sec": n_total * args.steps / dt,
             "ray_samples_per_sec_per_gpu": value / world,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                         "traffic_source": traffic_src,
                          "kernel": "nerf_mlp_kernel<rays>", "launches": int(launches_sum),
                          "avg_launch_ms": avg_launch_s * 1e3, "flop_per_launch": flop_per_launch,
                          "kernel_time_share": mlp_ms_sum * 1e-3 / world / dt},
