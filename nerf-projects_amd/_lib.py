@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libnerf_mi355x.so")
+LIB_PATH = os.environ.get("NERF_MI355X_LIB") or os.path.join(HERE, "libnerf_mi355x.so")
 
 NERF_MAX_SKIPS = 8
 NERF_NUM_SLOTS = 16

@@ -19,10 +19,12 @@
 //     layers chain with no LDS round trip and no cross-lane traffic: the only per-layer
 //     vector work is the ReLU (v_max) that also moves the tile into the operand set.
 //   * Weights (2.4 MB per network) are streamed L2 -> LDS in 32 KiB chunks by LDS-DMA
-//     (`global_load_lds_dwordx4`, 8 wave-instructions per wave per chunk), double-buffered:
-//     chunk c+1 is in flight while the four waves of the workgroup run the 128 MFMAs of
-//     chunk c (8192 matrix-pipe cycles per SIMD), then one barrier. A-fragments are read
-//     with `ds_read_b128` (4 k-steps per lane per read, lane-linear => conflict-free).
+//     (`global_load_lds_dwordx4`, 8 wave-instructions per wave per chunk) through a ring of
+//     three buffers: chunk c+2 is in flight and chunk c+1 resident while the four waves of
+//     the workgroup run the 128 MFMAs of chunk c (8192 matrix-pipe cycles per SIMD). One
+//     barrier per chunk, placed mid-chunk where its counters are already drained, so the MFMA
+//     stream runs across chunk boundaries. A-fragments are read with `ds_read_b128`
+//     (4 k-steps per lane per read, lane-linear => conflict-free).
 //   * Biases are pre-arranged per accumulator register and read from LDS straight into
 //     the accumulator tile (no MFMA, no VALU).
 //
@@ -44,37 +46,44 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 }
 
 // ---- weight-stream pipeline ------------------------------------------------------------
+// Three 32 KiB LDS buffers form a ring. While chunk c is being consumed, chunk c+1 is already
+// resident and chunk c+2 is in flight. The ONE barrier per chunk sits in the middle of the
+// chunk's MFMA sequence, at a step boundary where the in-order LDS counter is already drained:
+//   vmcnt(0)  -> this wave's share of chunk c+1 (issued a whole chunk ago) has landed
+//   s_barrier -> every wave's share has, and every wave has finished chunk c-1
+//   then issue chunk c+2 into the buffer chunk c-1 occupied.
+// Because chunk c+1 is visible from that point on, the last step of chunk c prefetches the first
+// A-fragments of chunk c+1, so the MFMA stream runs across chunk boundaries without a bubble.
+constexpr int kRing = 3;
+
 struct Pipe {
     const char* stream;   // packed chunks in HBM/L2
-    char* lds;            // two chunk buffers
+    char* lds;            // kRing chunk buffers
     int c;                // chunk being consumed
+    int b;                // ring slot of chunk c
     int n;                // chunks in the stream
     int wave;             // wave-uniform
     int lane;
 };
 
-__device__ __forceinline__ void prefetch_chunk(const Pipe& p, int chunk) {
+__device__ __forceinline__ int ring_next(int b, int k) {
+    b += k;
+    return b >= kRing ? b - kRing : b;
+}
+
+__device__ __forceinline__ void prefetch_chunk(const Pipe& p, int chunk, int slot) {
     const char* g = p.stream + (size_t)chunk * kChunkBytes + p.wave * 8192 + p.lane * 16;
-    char* l = p.lds + (chunk & 1) * kChunkBytes + p.wave * 8192;
+    char* l = p.lds + slot * kChunkBytes + p.wave * 8192;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
         __builtin_amdgcn_global_load_lds(GLB_PTR(g + i * 1024), LDS_PTR(l + i * 1024), 16, 0, 0);
 }
 
-// Start consuming chunk p.c: put chunk p.c+1 in flight into the other buffer (free since the
-// barrier that ended chunk p.c-1) and return this lane's fragment base in the current one.
-__device__ __forceinline__ const f32x4* chunk_begin(const Pipe& p) {
-    if (p.c + 1 < p.n) prefetch_chunk(p, p.c + 1);
-    return (const f32x4*)(p.lds + (p.c & 1) * kChunkBytes) + p.lane;
+__device__ __forceinline__ const f32x4* ring_frags(const Pipe& p, int slot) {
+    return (const f32x4*)(p.lds + slot * kChunkBytes) + p.lane;
 }
 
-// All waves are done reading chunk p.c and every wave's share of chunk p.c+1 has landed.
-__device__ __forceinline__ void chunk_end(Pipe& p) {
-    __syncthreads();   // hipcc emits s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier here
-    ++p.c;
-}
-
-// A-fragments of one (output tile, k-tile) pair: 4 x ds_read_b128 = 16 k-steps per lane
+// A-fragments of one step: 4 x ds_read_b128 = 16 k-steps per lane
 struct Frag16 {
     f32x4 q[4];
 };
@@ -84,63 +93,115 @@ __device__ __forceinline__ Frag16 read_frags(const f32x4* fr, int group) {
     for (int t4 = 0; t4 < 4; ++t4) f.q[t4] = fr[(group + t4) * 64];
     return f;
 }
-__device__ __forceinline__ void mma16(f32x16& acc, const Frag16& f, const f32x16& b) {
+// k-steps [LO, HI) of one step's 16
+template <int LO, int HI>
+__device__ __forceinline__ void mma_range(f32x16& acc, const Frag16& f, const f32x16& b) {
 #pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) {
-        acc = mfma(f.q[t4][0], b[4 * t4 + 0], acc);
-        acc = mfma(f.q[t4][1], b[4 * t4 + 1], acc);
-        acc = mfma(f.q[t4][2], b[4 * t4 + 2], acc);
-        acc = mfma(f.q[t4][3], b[4 * t4 + 3], acc);
-    }
+    for (int k = LO; k < HI; ++k) acc = mfma(f.q[k >> 2][k & 3], b[k], acc);
 }
-// One wave per SIMD has nobody to hide LDS latency behind, so the fragment reads are
-// software-pipelined by hand: the 4 reads of step n+1 are issued before the 16 MFMAs
-// (1024 matrix-pipe cycles) of step n. sched_group_barrier pins that order in the ISA.
-// The first MFMA of a step goes ahead of the next step's reads so that the s_waitcnt hipcc
-// inserts for it (in-order lgkmcnt) only ever waits for reads issued a whole step earlier.
-#define SCHED_READS() __builtin_amdgcn_sched_group_barrier(0x100, 4, 0)
-#define SCHED_MFMAS(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
 
-// one k-tile (16 k-steps) against NOT output tiles; groups ordered [ot][t4]
-template <int NOT>
-__device__ __forceinline__ void mma_ktile(f32x16 (&acc)[8], const f32x16& b, const f32x4* fr, int gbase = 0) {
-    Frag16 cur = read_frags(fr, gbase);
-    SCHED_READS();
+// One wave per SIMD has nobody to hide LDS latency behind, so fragment reads are software-
+// pipelined by hand: the reads of step n+1 are issued right after the FIRST MFMA of step n (so
+// the s_waitcnt hipcc inserts for that MFMA only waits for reads issued a whole step earlier),
+// and the other 15 MFMAs (960 matrix-pipe cycles) cover their latency.
+#define SCHED_STEP()                                          \
+    do {                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 15, 0);   \
+    } while (0)
+
+template <int S>
+struct StepTag {
+    static constexpr int value = S;
+};
+template <int LO, int HI>
+struct Range {
+    static constexpr int lo = LO, hi = HI;
+};
+
+// Consume the current chunk in NSTEP steps of 16 MFMAs. `body(StepTag<s>, Range<lo,hi>, frags)`
+// issues k-steps [lo,hi) of step s; `cur` holds the fragments of step 0 on entry and of the NEXT
+// chunk's step 0 on exit.
+//
+// The barrier follows step NSTEP/2-1 (see Pipe); the 8 LDS-DMA issues of chunk c+2 come right
+// after it.
+#ifndef NERF_MLP_SYNC_VARIANT
+#define NERF_MLP_SYNC_VARIANT 1
+#endif
+template <int S, int NSTEP, class Body>
+__device__ __forceinline__ void run_steps(Pipe& p, Frag16& cur, const f32x4* fr, const f32x4* fr_next, Body& body) {
+    if constexpr (S < NSTEP) {
+        Frag16 nxt = (S + 1 < NSTEP) ? read_frags(fr, (S + 1) * 4) : read_frags(fr_next, 0);
+        body(StepTag<S>{}, Range<0, 16>{}, cur);
+#if NERF_MLP_SYNC_VARIANT == 1
+        if constexpr (S == NSTEP / 2) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-    for (int ot = 0; ot < NOT; ++ot) {
-        Frag16 nxt = cur;
-        if (ot + 1 < NOT) nxt = read_frags(fr, gbase + (ot + 1) * 4);
-        mma16(acc[ot], cur, b);
-        if (ot + 1 < NOT) {
-            SCHED_MFMAS(1);
-            SCHED_READS();
-            SCHED_MFMAS(15);
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
         } else {
-            SCHED_MFMAS(16);
+            SCHED_STEP();
         }
+#else
+        SCHED_STEP();
+#endif
         cur = nxt;
+        if constexpr (S == NSTEP / 2 - 1) {
+            // keep the step's 15 trailing MFMAs above the barrier: the reads issued before them have
+            // returned by then, so the counters the barrier drains (vmcnt, lgkmcnt) are already empty
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            const int nx = p.c + 2 < p.n ? p.c + 2 : p.n - 1;   // past the end: reload the last chunk (harmless)
+            prefetch_chunk(p, nx, ring_next(p.b, 2));
+#if NERF_MLP_SYNC_VARIANT == 0
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+        run_steps<S + 1, NSTEP>(p, cur, fr, fr_next, body);
     }
 }
 
-// NKT k-tiles against ONE output tile; groups ordered [kt][t4]
+template <int NSTEP, class Body>
+__device__ __forceinline__ void consume_chunk(Pipe& p, Frag16& cur, Body body) {
+    const f32x4* fr = ring_frags(p, p.b);
+    const f32x4* fr_next = ring_frags(p, ring_next(p.b, 1));
+    run_steps<0, NSTEP>(p, cur, fr, fr_next, body);
+    ++p.c;
+    p.b = ring_next(p.b, 1);
+}
+
+// chunk kinds (group orders fixed by pack_weights.cpp) -------------------------------------------
+// one k-tile against 8 output tiles: step s = output tile s
+__device__ __forceinline__ void chunk_ktile8(Pipe& p, Frag16& cur, f32x16 (&acc)[8], const f32x16& b) {
+    consume_chunk<8>(p, cur, [&](auto tag, auto rng, const Frag16& f) {
+        mma_range<decltype(rng)::lo, decltype(rng)::hi>(acc[decltype(tag)::value], f, b);
+    });
+}
+// one k-tile against 4 output tiles (direction part of the view layer)
+__device__ __forceinline__ void chunk_ktile4(Pipe& p, Frag16& cur, f32x16 (&acc)[8], const f32x16& b) {
+    consume_chunk<4>(p, cur, [&](auto tag, auto rng, const Frag16& f) {
+        mma_range<decltype(rng)::lo, decltype(rng)::hi>(acc[decltype(tag)::value], f, b);
+    });
+}
+// two k-tiles against 4 output tiles (feature part of the view layer): steps 0-3 use b0, 4-7 use b1
+__device__ __forceinline__ void chunk_pair4(Pipe& p, Frag16& cur, f32x16 (&acc)[8], const f32x16& b0,
+                                            const f32x16& b1) {
+    consume_chunk<8>(p, cur, [&](auto tag, auto rng, const Frag16& f) {
+        constexpr int s = decltype(tag)::value;
+        mma_range<decltype(rng)::lo, decltype(rng)::hi>(acc[s & 3], f, s < 4 ? b0 : b1);
+    });
+}
+// NKT k-tiles against ONE output tile: step s = k-tile s
 template <int NKT>
-__device__ __forceinline__ void mma_row(f32x16& acc, const f32x16 (&b)[8], const f32x4* fr) {
-    Frag16 cur = read_frags(fr, 0);
-    SCHED_READS();
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        Frag16 nxt = cur;
-        if (kt + 1 < NKT) nxt = read_frags(fr, (kt + 1) * 4);
-        mma16(acc, cur, b[kt]);
-        if (kt + 1 < NKT) {
-            SCHED_MFMAS(1);
-            SCHED_READS();
-            SCHED_MFMAS(15);
-        } else {
-            SCHED_MFMAS(16);
-        }
-        cur = nxt;
-    }
+__device__ __forceinline__ void chunk_row(Pipe& p, Frag16& cur, f32x16& acc, const f32x16 (&b)[8]) {
+    consume_chunk<NKT>(p, cur, [&](auto tag, auto rng, const Frag16& f) {
+        mma_range<decltype(rng)::lo, decltype(rng)::hi>(acc, f, b[decltype(tag)::value]);
+    });
 }
 
 template <int N>
@@ -252,8 +313,9 @@ void nerf_mlp_kernel(const MlpLaunch a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
 
-    Pipe pipe{(const char*)a.stream, smem + kBiasLdsBytes, 0, a.n_chunks, wave, lane};
-    prefetch_chunk(pipe, 0);
+    Pipe pipe{(const char*)a.stream, smem + kBiasLdsBytes, 0, 0, a.n_chunks, wave, lane};
+    prefetch_chunk(pipe, 0, 0);
+    prefetch_chunk(pipe, a.n_chunks > 1 ? 1 : 0, 1);
     for (int i = threadIdx.x; i < a.n_bias_tiles * kBiasTileFloats; i += 256) bias_lds[i] = a.bias[i];
 
     const int64_t tile0 = (int64_t)blockIdx.x * kPointsPerGroup + wave * kPointsPerWave;
@@ -262,20 +324,15 @@ void nerf_mlp_kernel(const MlpLaunch a) {
 
     f32x16 x0, x1, dd;
     load_inputs<MODE>(a, pt, h, x0, x1, dd);
-    __syncthreads();   // chunk 0 and the bias block are in LDS
+    __syncthreads();   // chunks 0 and 1 and the bias block are in LDS
 
     f32x16 hid[8], acc[8];
+    Frag16 cur = read_frags(ring_frags(pipe, 0), 0);
 
     // layer 0: gamma(xyz) -> W (nerf.py:70-73)
     load_bias<8>(acc, bias_lds, 0, h);
-    {
-        const f32x4* fr = chunk_begin(pipe);
-        mma_ktile<8>(acc, x0, fr);
-        chunk_end(pipe);
-        fr = chunk_begin(pipe);
-        mma_ktile<8>(acc, x1, fr);
-        chunk_end(pipe);
-    }
+    chunk_ktile8(pipe, cur, acc, x0);
+    chunk_ktile8(pipe, cur, acc, x1);
     activate<8, true>(hid, acc);
 
     // trunk layers 1..D-1, then (with viewdirs) feature_linear as layer D without ReLU
@@ -286,27 +343,17 @@ void nerf_mlp_kernel(const MlpLaunch a) {
         if (is_feature) {
             // alpha_linear reads the post-ReLU trunk output before feature_linear (nerf.py:86-89)
             f32x16 al = *(const f32x16*)(bias_lds + ((8 * a.D) * 2 + h) * 16);
-            const f32x4* fr = chunk_begin(pipe);
-            mma_row<8>(al, hid, fr);
-            chunk_end(pipe);
+            chunk_row<8>(pipe, cur, al, hid);
             sigma = al[0];   // row 0 lives in register 0 of half-wave 0
         }
         load_bias<8>(acc, bias_lds, is_feature ? 8 * a.D + 1 : 8 * i, h);
         if (!is_feature && ((a.skip_in_mask >> i) & 1)) {
             // h = cat[input_pts, h] (nerf.py:79-80): the encoded inputs are still in registers
-            const f32x4* fr = chunk_begin(pipe);
-            mma_ktile<8>(acc, x0, fr);
-            chunk_end(pipe);
-            fr = chunk_begin(pipe);
-            mma_ktile<8>(acc, x1, fr);
-            chunk_end(pipe);
+            chunk_ktile8(pipe, cur, acc, x0);
+            chunk_ktile8(pipe, cur, acc, x1);
         }
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
-            const f32x4* fr = chunk_begin(pipe);
-            mma_ktile<8>(acc, hid[kt], fr);
-            chunk_end(pipe);
-        }
+        for (int kt = 0; kt < 8; ++kt) chunk_ktile8(pipe, cur, acc, hid[kt]);
         if (is_feature) activate<8, false>(hid, acc); else activate<8, true>(hid, acc);
     }
 
@@ -315,25 +362,12 @@ void nerf_mlp_kernel(const MlpLaunch a) {
         // views_linears[0] on cat[feature, gamma(dir)] (nerf.py:93-98): 4 output tiles
         load_bias<4>(acc, bias_lds, 8 * a.D + 9, h);
 #pragma unroll
-        for (int kp = 0; kp < 4; ++kp) {
-            const f32x4* fr = chunk_begin(pipe);
-            mma_ktile<4>(acc, hid[2 * kp], fr, 0);
-            mma_ktile<4>(acc, hid[2 * kp + 1], fr, 16);
-            chunk_end(pipe);
-        }
-        {
-            const f32x4* fr = chunk_begin(pipe);
-            mma_ktile<4>(acc, dd, fr);
-            chunk_end(pipe);
-        }
+        for (int kp = 0; kp < 4; ++kp) chunk_pair4(pipe, cur, acc, hid[2 * kp], hid[2 * kp + 1]);
+        chunk_ktile4(pipe, cur, acc, dd);
         activate<4, true>(hid, acc);
         // rgb_linear (nerf.py:101)
         f32x16 rgb = *(const f32x16*)(bias_lds + ((8 * a.D + 13) * 2 + h) * 16);
-        {
-            const f32x4* fr = chunk_begin(pipe);
-            mma_row<4>(rgb, hid, fr);
-            chunk_end(pipe);
-        }
+        chunk_row<4>(pipe, cur, rgb, hid);
         if (live && h == 0) {
             // outputs = cat[rgb, alpha] (nerf.py:106)
             f32x4 o = {rgb[0], rgb[1], rgb[2], sigma};
@@ -342,9 +376,7 @@ void nerf_mlp_kernel(const MlpLaunch a) {
     } else {
         // output_linear (nerf.py:109): rows 0..out_ch-1 of one tile
         f32x16 o = *(const f32x16*)(bias_lds + ((8 * a.D) * 2 + h) * 16);
-        const f32x4* fr = chunk_begin(pipe);
-        mma_row<8>(o, hid, fr);
-        chunk_end(pipe);
+        chunk_row<8>(pipe, cur, o, hid);
         if (live) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -353,6 +385,8 @@ void nerf_mlp_kernel(const MlpLaunch a) {
             }
         }
     }
+    // the ring's trailing (clamped) prefetches must land before this workgroup's LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 hipError_t launch_mlp(const MlpLaunch& a, int mode, hipStream_t s) {
@@ -360,8 +394,8 @@ hipError_t launch_mlp(const MlpLaunch& a, int mode, hipStream_t s) {
     const int64_t groups = (a.n_points + kPointsPerGroup - 1) / kPointsPerGroup;
     if (groups > 0x7fffffffLL) return hipErrorInvalidValue;
     const dim3 grid((unsigned)groups), block(256);
-    const size_t lds = kBiasLdsBytes + 2 * kChunkBytes;
-    // 80 KiB of dynamic LDS is above the 64 KiB default cap: raise it once per device and mode
+    const size_t lds = kBiasLdsBytes + kRing * kChunkBytes;
+    // 112 KiB of dynamic LDS is above the 64 KiB default cap: raise it once per device and mode
     static bool raised[64][3] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
