@@ -165,6 +165,35 @@ typedef struct nerf_render_args {
 
 int nerf_render_rays(nerf_ctx* ctx, const nerf_render_args* args);
 
+/* Ray generation ---------------------------------------------------
+ * get_rays (nerf/nerf_helpers.py:222-296) + the packing done by render() (nerf.ipynb:596-629):
+ * viewdir normalisation before the NDC warp and before the c2w_staticcam override, optional
+ * ndc_rays (nerf_helpers.py:311-369, called with near = 1.0), near/far columns. Writes the
+ * [n_pixels, 8|11] ray record for flat pixel indices [first_pixel, first_pixel + n_pixels) of the
+ * H x W image (row-major, index = row*W + col), so a rank can generate only its own shard.
+ */
+typedef struct nerf_camera {
+    int32_t H, W;
+    float fx, fy, cx, cy;       /* K[0][0], K[1][1], K[0][2], K[1][2] as fp32 (what torch casts to) */
+    float c2w[12];              /* camera-to-world [3,4] row-major                               */
+    float c2w_static[12];       /* c2w_staticcam, used when has_static != 0                       */
+    int32_t has_static;
+    int32_t ndc;
+    double ndc_focal;           /* K[0][0] as the Python float that ndc_rays receives             */
+    float near, far;            /* columns 6 and 7                                                */
+    int32_t use_viewdirs;       /* 11 columns instead of 8                                        */
+} nerf_camera;
+
+int nerf_generate_rays(nerf_ctx* ctx, const nerf_camera* cam, int64_t first_pixel, int64_t n_pixels,
+                       float* rays /*[dev] [n_pixels, 8|11]*/, void* stream);
+
+/* Image metrics -----------------------------------------------------
+ * calculate_ssim (nerf/nerf_helpers.py:21-111): separable 11-tap Gaussian (sigma 1.5), zero padded,
+ * on [H,W,3] images clamped to [0,max_val]; img2mse (nerf_helpers.py:8). Results are written to
+ * device scalars: out[0] = mean SSIM, out[1] = MSE of the clamped images. */
+int nerf_image_metrics(nerf_ctx* ctx, const float* img1 /*[dev] [H,W,3]*/, const float* img2 /*[dev]*/,
+                       int H, int W, float max_val, float* out /*[dev] [2]*/, void* stream);
+
 /* Measurement hooks ------------------------------------------------------------------
  * Accumulated device time of the dominant kernel (the fused encode+MLP kernel),
  * measured with HIP events recorded on the launch stream around every launch while

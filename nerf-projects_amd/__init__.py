@@ -6,9 +6,10 @@ Importing the package never touches the GPU; the first call that needs it loads
 ``libnerf_mi355x.so`` and raises if the library or a gfx950 device is missing.
 """
 from . import synthetic  # noqa: F401
-from .host import (NeRF, NetworkQuery, batchify, batchify_rays, get_context, get_embedder, get_rays,  # noqa: F401
-                   get_rays_np, img2mse, make_network_query_fn, mse2psnr, ndc_rays, pack_rays, raw2outputs,
-                   render, render_rays, run_network, sample_pdf, to8b)
+from .host import (NeRF, NetworkQuery, batchify, batchify_rays, calculate_lpips, calculate_metrics,  # noqa: F401
+                   calculate_ssim, create_nerf, generate_rays, get_context, get_embedder, get_rays, get_rays_np,
+                   img2mse, load_checkpoint, make_network_query_fn, mse2psnr, ndc_rays, pack_rays, raw2outputs,
+                   render, render_path, render_rays, run_network, sample_pdf, to8b, write_png)
 from .sharded import gather_frame, render_sharded, shard_bounds  # noqa: F401
 
 __version__ = "0.1.0"

@@ -16,7 +16,7 @@ EXPORTS = (
     "nerf_last_error", "nerf_version", "nerf_device_count", "nerf_ctx_create", "nerf_ctx_destroy",
     "nerf_load_weights", "nerf_num_weight_tensors", "nerf_embed", "nerf_mlp_forward", "nerf_run_network",
     "nerf_raw2outputs", "nerf_sample_pdf", "nerf_render_rays", "nerf_profile_enable", "nerf_profile_read",
-    "nerf_workspace_bytes",
+    "nerf_workspace_bytes", "nerf_generate_rays", "nerf_image_metrics",
 )
 
 
@@ -38,6 +38,13 @@ class RenderArgs(C.Structure):
                 ("disp0", _FP), ("acc0", _FP), ("z_std", _FP), ("z_vals_coarse", _FP),
                 ("weights_coarse", _FP), ("z_samples", _FP), ("z_vals_fine", _FP), ("weights_fine", _FP),
                 ("depth_map", _FP), ("z_vals_fine_in", _FP), ("stream", C.c_void_p)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("c2w", C.c_float * 12), ("c2w_static", C.c_float * 12),
+                ("has_static", C.c_int32), ("ndc", C.c_int32), ("ndc_focal", C.c_double), ("near", C.c_float),
+                ("far", C.c_float), ("use_viewdirs", C.c_int32)]
 
 
 _lib = None
@@ -88,6 +95,10 @@ def load():
     lib.nerf_profile_enable.argtypes = [vp, i32]
     lib.nerf_profile_read.restype = i32
     lib.nerf_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64), i32]
+    lib.nerf_generate_rays.restype = i32
+    lib.nerf_generate_rays.argtypes = [vp, C.POINTER(Camera), i64, i64, vp, vp]
+    lib.nerf_image_metrics.restype = i32
+    lib.nerf_image_metrics.argtypes = [vp, vp, vp, i32, i32, C.c_float, vp, vp]
     lib.nerf_workspace_bytes.restype = i64
     lib.nerf_workspace_bytes.argtypes = [vp]
     _lib = lib

@@ -434,6 +434,45 @@ int nerf_render_rays(nerf_ctx* c, const nerf_render_args* r) {
     return NERF_OK;
 }
 
+int nerf_generate_rays(nerf_ctx* c, const nerf_camera* cam, int64_t first_pixel, int64_t n_pixels, float* rays,
+                       void* stream) {
+    if (!c || !cam || first_pixel < 0 || n_pixels < 0) {
+        set_error("nerf_generate_rays: invalid argument");
+        return NERF_E_INVALID;
+    }
+    if (cam->H <= 0 || cam->W <= 0 || first_pixel + n_pixels > (int64_t)cam->H * cam->W) {
+        set_error("nerf_generate_rays: pixels [%lld, %lld) outside the %dx%d image", (long long)first_pixel,
+                  (long long)(first_pixel + n_pixels), cam->H, cam->W);
+        return NERF_E_INVALID;
+    }
+    if (n_pixels == 0) return NERF_OK;
+    if (!rays) {
+        set_error("nerf_generate_rays: rays is NULL");
+        return NERF_E_INVALID;
+    }
+    DeviceGuard g(c->device);
+    HIP_TRY(launch_raygen(*cam, first_pixel, n_pixels, rays, (hipStream_t)stream));
+    return NERF_OK;
+}
+
+int nerf_image_metrics(nerf_ctx* c, const float* img1, const float* img2, int H, int W, float max_val, float* out,
+                       void* stream) {
+    if (!c || !img1 || !img2 || !out || H <= 0 || W <= 0) {
+        set_error("nerf_image_metrics: invalid argument");
+        return NERF_E_INVALID;
+    }
+    DeviceGuard g(c->device);
+    const size_t total = (size_t)H * W * 3;
+    const size_t blocks = (total + 255) / 256;
+    int rc = ensure_workspace(c, arena_bytes({5 * total, 4 * blocks + 16}));
+    if (rc != NERF_OK) return rc;
+    Arena ar(c->ws);
+    float* tmp = ar.take(5 * total);
+    double* partial = (double*)ar.take(4 * blocks + 16);
+    HIP_TRY(launch_image_metrics(img1, img2, H, W, max_val, tmp, partial, out, (hipStream_t)stream));
+    return NERF_OK;
+}
+
 int nerf_profile_enable(nerf_ctx* c, int on) {
     if (!c) return NERF_E_INVALID;
     c->profiling = on != 0;

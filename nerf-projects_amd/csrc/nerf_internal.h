@@ -81,6 +81,10 @@ hipError_t launch_sample_pdf(const float* bins, const float* weights, int w_ld, 
                              int n_samples, float* samples, float* z_merged, float* z_std,
                              hipStream_t s);
 
+hipError_t launch_raygen(const nerf_camera& cam, int64_t first, int64_t n, float* rays, hipStream_t s);
+hipError_t launch_image_metrics(const float* a, const float* b, int H, int W, float max_val, float* tmp,
+                                double* partial, float* out, hipStream_t s);
+
 void set_error(const char* fmt, ...);
 
 }  // namespace nerf

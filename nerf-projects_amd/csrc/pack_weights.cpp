@@ -99,8 +99,13 @@ int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors,
         set_error("unsupported input_ch=%d (3 + 6*multires, multires <= 10)", a.input_ch);
         return NERF_E_INVALID;
     }
-    if (a.input_ch_views < 3 || a.input_ch_views > 27 || (a.input_ch_views - 3) % 6 != 0) {
+    // without viewdirs views_linears exists but is never evaluated (create_nerf passes input_ch_views = 0)
+    if (a.use_viewdirs && (a.input_ch_views < 3 || a.input_ch_views > 27 || (a.input_ch_views - 3) % 6 != 0)) {
         set_error("unsupported input_ch_views=%d (3 + 6*multires_views, multires_views <= 4)", a.input_ch_views);
+        return NERF_E_INVALID;
+    }
+    if (!a.use_viewdirs && (a.input_ch_views < 0 || a.input_ch_views > 64)) {
+        set_error("unsupported input_ch_views=%d", a.input_ch_views);
         return NERF_E_INVALID;
     }
     if (a.n_skips < 0 || a.n_skips > NERF_MAX_SKIPS) {

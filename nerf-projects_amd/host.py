@@ -16,12 +16,13 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import NerfArch, RenderArgs, check
+from ._lib import Camera, NerfArch, RenderArgs, check
 
 __all__ = [
     "NeRF", "get_embedder", "batchify", "run_network", "raw2outputs", "sample_pdf", "render_rays",
     "batchify_rays", "render", "get_rays", "get_rays_np", "ndc_rays", "make_network_query_fn",
-    "get_context", "img2mse", "mse2psnr", "to8b",
+    "get_context", "img2mse", "mse2psnr", "to8b", "generate_rays", "render_path", "calculate_ssim",
+    "calculate_lpips", "calculate_metrics", "create_nerf", "load_checkpoint",
 ]
 
 
@@ -622,16 +623,220 @@ def pack_rays(H, W, K, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewd
     return packed, sh
 
 
+def _mat34(m):
+    m = m.detach().cpu().numpy() if torch.is_tensor(m) else np.asarray(m)
+    m = np.asarray(m, dtype=np.float32)
+    if m.shape[0] < 3 or m.shape[1] < 4:
+        raise RuntimeError(f"camera-to-world matrix must be at least [3,4], got {m.shape}")
+    return np.ascontiguousarray(m[:3, :4]).reshape(-1)
+
+
+def generate_rays(H, W, K, c2w, ndc=True, near=0., far=1., use_viewdirs=False, c2w_staticcam=None,
+                  first_pixel=0, n_pixels=None, device=None):
+    """The ``[n_pixels, 8|11]`` ray record of ``render()`` (nerf.ipynb:596-629) generated on the GPU by
+    one kernel (``get_rays`` + viewdir normalisation + optional ``ndc_rays`` + near/far columns) for the
+    flat pixel range ``[first_pixel, first_pixel + n_pixels)``: no host ray generation, no 28 MB H2D copy,
+    and a rank of a sharded render only ever materialises its own shard."""
+    ctx = get_context(device)
+    cam = Camera()
+    cam.H, cam.W = int(H), int(W)
+    # torch computes (i - K[0][2]) / K[0][0] in fp32 with the Python/numpy scalars cast to fp32
+    cam.fx, cam.fy, cam.cx, cam.cy = float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2])
+    cam.c2w = (C.c_float * 12)(*_mat34(c2w))
+    if c2w_staticcam is not None and use_viewdirs:
+        cam.c2w_static = (C.c_float * 12)(*_mat34(c2w_staticcam))
+        cam.has_static = 1
+    cam.ndc, cam.ndc_focal = int(bool(ndc)), float(K[0][0])
+    cam.near, cam.far, cam.use_viewdirs = float(near), float(far), int(bool(use_viewdirs))
+    total = cam.H * cam.W
+    n = total - first_pixel if n_pixels is None else int(n_pixels)
+    out = torch.empty((n, 11 if use_viewdirs else 8), device=ctx.device, dtype=torch.float32)
+    check(ctx.lib.nerf_generate_rays(ctx.handle, C.byref(cam), int(first_pixel), n, _ptr(out), ctx.stream()))
+    return out
+
+
 def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
            c2w_staticcam=None, **kwargs):
-    """``[rgb_map, disp_map, acc_map, extras]`` reshaped to the ray grid (nerf.ipynb:558-640)."""
+    """``[rgb_map, disp_map, acc_map, extras]`` reshaped to the ray grid (nerf.ipynb:558-640).
+    With ``c2w`` the rays are generated on the GPU (:func:`generate_rays`); a ``rays`` tuple is
+    packed with torch ops exactly as the reference does."""
     model_device = next(kwargs['network_fn'].parameters()).device
-    packed, sh = pack_rays(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, device=model_device)
+    if c2w is not None:
+        packed = generate_rays(H, W, K, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, device=model_device)
+        sh = (H, W, 3)
+    else:
+        packed, sh = pack_rays(H, W, K, rays, None, ndc, near, far, use_viewdirs, c2w_staticcam,
+                               device=model_device)
     all_ret = batchify_rays(packed, chunk, **kwargs)
     for k in all_ret:
         all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
     k_extract = ['rgb_map', 'disp_map', 'acc_map']
     return [all_ret[k] for k in k_extract] + [{k: all_ret[k] for k in all_ret if k not in k_extract}]
+
+
+def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0,
+                calculate_metrics=False, metrics_include_lpips=True, metrics_device='cuda'):
+    """Render a sequence of poses (nerf.ipynb:650-758): returns ``(rgbs, disps)`` as numpy arrays, or
+    ``(rgbs, disps, avg_metrics)`` with ``calculate_metrics``; optionally writes 8-bit PNGs."""
+    import os
+    import time
+    H, W, focal = hwf
+    if render_factor != 0:
+        H, W, focal = H // render_factor, W // render_factor, focal / render_factor
+    rgbs, disps = [], []
+    want_metrics = calculate_metrics and gt_imgs is not None
+    all_metrics = {'psnr': [], 'ssim': [], 'mse': []}
+    if metrics_include_lpips:
+        all_metrics['lpips'] = []
+    t = time.time()
+    for i, c2w in enumerate(render_poses):
+        print(i, time.time() - t)
+        t = time.time()
+        rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
+        rgbs.append(rgb.cpu().numpy())
+        disps.append(disp.cpu().numpy())
+        if i == 0:
+            print(rgb.shape, disp.shape)
+        if want_metrics and render_factor == 0 and i < len(gt_imgs):
+            m = globals()['calculate_metrics'](rgb, gt_imgs[i], include_lpips=metrics_include_lpips,
+                                               device=metrics_device)
+            for key in all_metrics:
+                if m.get(key) is not None:
+                    all_metrics[key].append(m[key])
+            print(f"Frame {i} - PSNR: {m['psnr']:.2f}, SSIM: {m['ssim']:.4f}")
+        if savedir is not None:
+            write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))
+    rgbs, disps = np.stack(rgbs, 0), np.stack(disps, 0)
+    if want_metrics:
+        avg = {}
+        for key, values in all_metrics.items():
+            if values:
+                avg[f'avg_{key}'] = np.mean(values)
+                avg[f'std_{key}'] = np.std(values)
+        return rgbs, disps, avg
+    return rgbs, disps
+
+
+def write_png(path, img8):
+    """Minimal 8-bit RGB/RGBA/gray PNG writer (stands in for ``imageio.imwrite``, nerf.ipynb:728)."""
+    import struct
+    import zlib
+    img8 = np.ascontiguousarray(img8, dtype=np.uint8)
+    if img8.ndim == 2:
+        img8 = img8[..., None]
+    h, w, c = img8.shape
+    color = {1: 0, 3: 2, 4: 6}[c]
+    raw = b"".join(b"\x00" + img8[r].tobytes() for r in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, color, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+# ----------------------------------------------------------------------------------------------
+# model construction / checkpoints (nerf.ipynb:876-960)
+# ----------------------------------------------------------------------------------------------
+
+def load_checkpoint(path):
+    """``torch.load`` of a reference checkpoint ``{global_step, network_fn_state_dict,
+    network_fine_state_dict, optimizer_state_dict}`` (written at nerf.ipynb:1290-1299)."""
+    return torch.load(path, map_location="cpu", weights_only=False)
+
+
+def create_nerf(args, device=None):
+    """``create_nerf`` (nerf.ipynb:876-960) for rendering: embedders, coarse/fine models, the query
+    function, checkpoint reload and the train/test render kwargs. Training state (``grad_vars``,
+    ``optimizer``) is out of this build's scope and returned as ``None``."""
+    import os
+    embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
+    input_ch_views, embeddirs_fn = 0, None
+    if args.use_viewdirs:
+        embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
+    output_ch = 5 if args.N_importance > 0 else 4
+    skips = [4]
+    model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=skips,
+                 input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs, device=device)
+    model_fine = None
+    if args.N_importance > 0:
+        model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch,
+                          skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs, device=device)
+    network_query_fn = make_network_query_fn(embed_fn, embeddirs_fn, args.netchunk)
+    start = 0
+    ckpt_dir = os.path.join(args.basedir, args.expname, "checkpoints")
+    ft_path = getattr(args, "ft_path", None)
+    if ft_path is not None and ft_path != 'None':
+        ckpts = [ft_path]
+    else:
+        ckpts = [os.path.join(ckpt_dir, f) for f in sorted(os.listdir(ckpt_dir)) if 'tar' in f] \
+            if os.path.isdir(ckpt_dir) else []
+    print('Found ckpts', ckpts)
+    if len(ckpts) > 0 and not getattr(args, "no_reload", False):
+        print('Reloading from', ckpts[-1])
+        ckpt = load_checkpoint(ckpts[-1])
+        start = ckpt['global_step']
+        model.load_state_dict(ckpt['network_fn_state_dict'])
+        if model_fine is not None:
+            model_fine.load_state_dict(ckpt['network_fine_state_dict'])
+    render_kwargs_train = {
+        'network_query_fn': network_query_fn, 'perturb': args.perturb, 'N_importance': args.N_importance,
+        'network_fine': model_fine, 'N_samples': args.N_samples, 'network_fn': model,
+        'use_viewdirs': args.use_viewdirs, 'white_bkgd': args.white_bkgd, 'raw_noise_std': args.raw_noise_std,
+    }
+    if args.dataset_type != 'llff' or args.no_ndc:
+        print('Not ndc!')
+        render_kwargs_train['ndc'] = False
+        render_kwargs_train['lindisp'] = args.lindisp
+    render_kwargs_test = dict(render_kwargs_train)
+    render_kwargs_test['perturb'] = False
+    render_kwargs_test['raw_noise_std'] = 0.
+    return render_kwargs_train, render_kwargs_test, start, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# image metrics (nerf_helpers.py:8-214)
+# ----------------------------------------------------------------------------------------------
+
+def _image_metrics(img1, img2, max_val=1.0):
+    ctx = get_context(img1.device if torch.is_tensor(img1) and img1.is_cuda else
+                      (img2.device if torch.is_tensor(img2) and img2.is_cuda else None))
+    a, b = _dev(img1, ctx), _dev(img2, ctx)
+    if a.dim() != 3 or a.shape != b.shape or a.shape[-1] != 3:
+        raise ValueError(f"Expected 3D tensor [H, W, C], got {tuple(a.shape)} and {tuple(b.shape)}")
+    out = torch.empty(2, device=ctx.device, dtype=torch.float32)
+    check(ctx.lib.nerf_image_metrics(ctx.handle, _ptr(a), _ptr(b), a.shape[0], a.shape[1], float(max_val),
+                                     _ptr(out), ctx.stream()))
+    return out
+
+
+def calculate_ssim(img1, img2, max_val=1.0, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03, return_map=False):
+    """Mean SSIM of two ``[H,W,3]`` images (nerf_helpers.py:21-111). The kernel implements the
+    reference's defaults (11-tap, sigma 1.5, k1 0.01, k2 0.03); other settings raise."""
+    if (filter_size, filter_sigma, k1, k2) != (11, 1.5, 0.01, 0.03) or return_map:
+        raise NotImplementedError("calculate_ssim: only the reference defaults are implemented on the GPU")
+    return float(_image_metrics(img1, img2, max_val)[0].item())
+
+
+def calculate_lpips(img1, img2, net='vgg', device='cuda', normalize=True):
+    """nerf_helpers.py:114-146 needs the ``lpips`` package and its VGG weights (a remote fetch);
+    neither exists offline, so this raises exactly as the reference does when ``lpips`` is missing."""
+    import lpips  # noqa: F401  (ImportError, as in the reference)
+    raise RuntimeError("LPIPS is outside this build's scope (SURVEY.md section 2 row 7)")
+
+
+def calculate_metrics(img1, img2, include_lpips=True, lpips_net='vgg', device='cuda'):
+    """``{'mse','psnr','ssim'[, 'lpips']}`` (nerf_helpers.py:148-214); SSIM and MSE come from one GPU pass."""
+    out = _image_metrics(img1, img2, 1.0).cpu()
+    mse = float(out[1])
+    metrics = {'mse': mse, 'psnr': float(mse2psnr(torch.tensor(mse))), 'ssim': float(out[0])}
+    if include_lpips:
+        try:
+            metrics['lpips'] = calculate_lpips(img1, img2, net=lpips_net, device=device)
+        except Exception as e:      # same soft failure as the reference (nerf_helpers.py:207-212)
+            print(f"Warning: Could not calculate LPIPS: {e}")
+            metrics['lpips'] = None
+    return metrics
 
 
 # ----------------------------------------------------------------------------------------------

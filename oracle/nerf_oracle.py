@@ -454,6 +454,51 @@ def make_query_fn(embed_fn, embeddirs_fn, netchunk=1024 * 64):
         inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=netchunk)
 
 
+def calculate_ssim(img1, img2, max_val=1.0, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03):
+    """Mean SSIM of two [H,W,3] images, restating nerf_helpers.py:21-111 (tf.image.ssim style):
+    separable Gaussian window, zero padding, sigma clamps, mean over all pixels and channels."""
+    a = np.clip(np.asarray(img1, dtype=F32), 0, max_val)
+    b = np.clip(np.asarray(img2, dtype=F32), 0, max_val)
+    hw = filter_size // 2
+    shift = (2 * hw - filter_size + 1) / 2
+    f_i = ((np.arange(filter_size) - hw + shift) / filter_sigma).astype(F32) ** 2           # :59
+    filt = np.exp(F32(-0.5) * f_i).astype(F32)
+    filt = (filt / np.sum(filt, dtype=F32)).astype(F32)                                     # :60-62
+
+    def conv(z, axis):                                                                      # zero-padded 'same'
+        pad = [(0, 0)] * z.ndim
+        pad[axis] = (hw, hw)
+        zp = np.pad(z, pad)
+        out = np.zeros_like(z)
+        for k in range(filter_size):
+            sl = [slice(None)] * z.ndim
+            sl[axis] = slice(k, k + z.shape[axis])
+            out = out + filt[k] * zp[tuple(sl)]
+        return out.astype(F32)
+
+    def filt_fn(z):                                                                         # :63-73
+        return conv(conv(z, 1), 0)
+
+    mu0, mu1 = filt_fn(a), filt_fn(b)
+    mu00, mu11, mu01 = mu0 * mu0, mu1 * mu1, mu0 * mu1
+    s00 = np.maximum(filt_fn(a * a) - mu00, F32(0))                                         # :80-86
+    s11 = np.maximum(filt_fn(b * b) - mu11, F32(0))
+    s01 = filt_fn(a * b) - mu01
+    s01 = np.sign(s01) * np.minimum(np.sqrt(s00 * s11), np.abs(s01))                        # :87-89
+    c1, c2 = F32((k1 * max_val) ** 2), F32((k2 * max_val) ** 2)
+    numer = (F32(2) * mu01 + c1) * (F32(2) * s01 + c2)
+    denom = (mu00 + mu11 + c1) * (s00 + s11 + c2)
+    return float(np.mean((numer / denom).astype(np.float64)))                               # :93-99
+
+
+def calculate_metrics(img1, img2):
+    """mse / psnr / ssim of nerf_helpers.py:148-214 (LPIPS needs the absent ``lpips`` package)."""
+    a = np.clip(np.asarray(img1, dtype=F32), 0, 1)
+    b = np.clip(np.asarray(img2, dtype=F32), 0, 1)
+    mse = float(img2mse(a, b))
+    return {'mse': mse, 'psnr': float(mse2psnr(mse)), 'ssim': calculate_ssim(img1, img2)}
+
+
 def img2mse(x, y):
     """nerf_helpers.py:8-11."""
     return np.mean((np.asarray(x, F32) - np.asarray(y, F32)) ** 2, dtype=F32)

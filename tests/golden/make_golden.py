@@ -337,6 +337,54 @@ def gold_render():
          **{k: n(v) for k, v in extras.items()})
 
 
+def gold_ray_packing():
+    """The ray record exactly as the reference's own render() hands it to batchify_rays
+    (nerf.ipynb:596-632), captured with a spy; four camera configurations on a 30x40 image."""
+    captured = {}
+
+    def spy(rays_flat, chunk=1024 * 32, **kwargs):
+        captured["rays"] = n(rays_flat)
+        z = torch.zeros(rays_flat.shape[0])
+        return {"rgb_map": torch.zeros(rays_flat.shape[0], 3), "disp_map": z, "acc_map": z}
+
+    orig = NS["batchify_rays"]
+    NS["batchify_rays"] = spy
+    try:
+        H, W = 30, 40
+        Kl = synthetic.intrinsics(H, W, synthetic.blender_focal(W))
+        c2w = torch.from_numpy(synthetic.pose_spherical(30.0, -30.0, 4.0)[:3, :4])
+        c2w_s = torch.from_numpy(synthetic.pose_spherical(-70.0, -20.0, 4.0)[:3, :4])
+        Kf = synthetic.intrinsics(H, W, 32.0)
+        c2w_f = torch.from_numpy(synthetic.llff_like_pose()[:3, :4])
+        dummy = ref_model(7)
+        out = dict(H=H, W=W, K_lego=Kl, K_fern=Kf, c2w=n(c2w), c2w_static=n(c2w_s), c2w_fern=n(c2w_f))
+        NS["render"](H, W, Kl, c2w=c2w, ndc=False, near=2., far=6., use_viewdirs=True, network_fn=dummy)
+        out["lego"] = captured["rays"]
+        NS["render"](H, W, Kl, c2w=c2w, ndc=False, near=2., far=6., use_viewdirs=True, c2w_staticcam=c2w_s,
+                     network_fn=dummy)
+        out["static"] = captured["rays"]
+        NS["render"](H, W, Kl, c2w=c2w, ndc=False, near=2., far=6., use_viewdirs=False, network_fn=dummy)
+        out["noview"] = captured["rays"]
+        NS["render"](H, W, Kf, c2w=c2w_f, ndc=True, near=0., far=1., use_viewdirs=True, network_fn=dummy)
+        out["ndc"] = captured["rays"]
+    finally:
+        NS["batchify_rays"] = orig
+    save("ray_packing", **out)
+
+
+def gold_metrics():
+    """calculate_metrics / calculate_ssim of nerf_helpers.py on seeded images (LPIPS needs `lpips`: absent)."""
+    rs = np.random.RandomState(105)
+    H, W = 37, 53
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = np.stack([0.5 + 0.5 * np.sin(xx / 5.0), 0.5 + 0.5 * np.cos(yy / 7.0), (xx + yy) / (H + W)], -1)
+    a = (base + rs.normal(0, 0.02, size=base.shape)).astype(np.float32)     # slightly outside [0,1]: clamps matter
+    b = (base + rs.normal(0, 0.08, size=base.shape)).astype(np.float32)
+    m = ref_helpers.calculate_metrics(a, b, include_lpips=False)
+    ssim_same = ref_helpers.calculate_ssim(a, a)
+    save("metrics", img1=a, img2=b, mse=m["mse"], psnr=m["psnr"], ssim=m["ssim"], ssim_same=ssim_same)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -348,3 +396,5 @@ if __name__ == "__main__":
     gold_sample_pdf()
     gold_render_rays()
     gold_render()
+    gold_ray_packing()
+    gold_metrics()

@@ -267,7 +267,9 @@ def test_render_small_frame(N, nets):
     # rays given as a tuple instead of c2w (nerf.ipynb:604-605)
     ro, rd = N.get_rays(H, W, g["K"], torch.from_numpy(g["c2w"]).cuda())
     rgb3 = N.render(H, W, g["K"], chunk=64, rays=(ro, rd), ndc=False, near=2., far=6., use_viewdirs=True, **kw)[0]
-    assert torch.equal(rgb, rgb3)
+    # torch's own GPU get_rays rounds the 3-term sums differently from the ray-generation kernel (which
+    # follows the reference's CPU order), so this route agrees to rounding, not to the bit
+    check_end_to_end(cpu(rgb3).reshape(-1, 3), cpu(rgb).reshape(-1, 3))
 
 
 def test_ray_packing(N):
@@ -325,3 +327,126 @@ def test_errors_are_exceptions(N, nets):
         N.render_rays(torch.zeros(4, 11).cuda(), torch.nn.Linear(3, 3), q, N_samples=8)
     empty = N.render_rays(torch.zeros(0, 11).cuda(), net_c, q, N_samples=8, N_importance=8, network_fine=net_f)
     assert empty["rgb_map"].shape == (0, 3)
+
+
+# ---- section 8 "next" rows: ray generation, frame loop, checkpoints, metrics ---------------------------
+
+def test_generate_rays_all_camera_modes(N):
+    g = load_golden("ray_packing")
+    H, W = int(g["H"]), int(g["W"])
+    cases = {
+        "lego": dict(K=g["K_lego"], c2w=g["c2w"], ndc=False, near=2., far=6., use_viewdirs=True),
+        "static": dict(K=g["K_lego"], c2w=g["c2w"], ndc=False, near=2., far=6., use_viewdirs=True,
+                       c2w_staticcam=g["c2w_static"]),
+        "noview": dict(K=g["K_lego"], c2w=g["c2w"], ndc=False, near=2., far=6., use_viewdirs=False),
+        "ndc": dict(K=g["K_fern"], c2w=g["c2w_fern"], ndc=True, near=0., far=1., use_viewdirs=True),
+    }
+    for name, kw in cases.items():
+        K = kw.pop("K")
+        rays = cpu(N.generate_rays(H, W, K, **kw))
+        assert rays.shape == g[name].shape, name
+        np.testing.assert_allclose(rays, g[name], rtol=0, atol=2e-6, err_msg=name)
+        # a shard generated on its own equals the same rows of the full frame, bit for bit
+        part = cpu(N.generate_rays(H, W, K, first_pixel=333, n_pixels=500, **kw))
+        assert np.array_equal(part, rays[333:833]), name
+    with pytest.raises(RuntimeError):
+        N.generate_rays(H, W, g["K_lego"], g["c2w"], first_pixel=H * W - 3, n_pixels=10)
+
+
+def test_generate_rays_full_frame(N, O):
+    """800x800 lego frame and 1008x756 NDC frame (BASELINE configs C2/C4) vs the oracle's packing."""
+    for (H, W, cam, ndc) in ((800, 800, synthetic.lego_camera, False), (756, 1008, synthetic.fern_camera, True)):
+        K, c2w, near, far = cam(H, W)
+        rays = cpu(N.generate_rays(H, W, K, c2w, ndc=ndc, near=near, far=far, use_viewdirs=True))
+        want, _ = O.pack_rays(H, W, K, c2w=c2w, ndc=ndc, near=near, far=far, use_viewdirs=True)
+        assert rays.shape == want.shape == (H * W, 11)
+        np.testing.assert_allclose(rays, want, rtol=0, atol=2e-6)
+        assert np.abs(np.linalg.norm(rays[:, 8:11], axis=-1) - 1).max() <= 1e-6
+
+
+def test_image_metrics(N):
+    g = load_golden("metrics")
+    m = N.calculate_metrics(gpu(g["img1"]), gpu(g["img2"]), include_lpips=False)
+    assert abs(m["mse"] - float(g["mse"])) <= 1e-7
+    assert abs(m["psnr"] - float(g["psnr"])) <= 1e-3
+    assert abs(m["ssim"] - float(g["ssim"])) <= 2e-5
+    assert abs(N.calculate_ssim(g["img1"], g["img1"]) - float(g["ssim_same"])) <= 5e-6    # numpy inputs too
+    soft = N.calculate_metrics(gpu(g["img1"]), gpu(g["img2"]))       # lpips missing: soft failure like the reference
+    assert soft["lpips"] is None
+    with pytest.raises(ValueError):
+        N.calculate_ssim(torch.zeros(4, 4).cuda(), torch.zeros(4, 4).cuda())
+
+
+class _Args:
+    """The fields create_nerf reads from the YAML-backed args (nerf/yaml/lego_blender200k_fullres)."""
+    multires, multires_views, i_embed = 10, 4, 0
+    netdepth = netdepth_fine = 8
+    netwidth = netwidth_fine = 256
+    netchunk = 65536
+    N_samples, N_importance = 16, 16
+    use_viewdirs, white_bkgd, lindisp = True, True, False
+    perturb, raw_noise_std = 1.0, '1e0'
+    dataset_type, no_ndc = 'blender', False
+    ft_path, no_reload = None, False
+    expname = 'exp'
+
+
+def test_create_nerf_checkpoint_and_render_path(N, O, weights_pair, tmp_path):
+    sd_c, sd_f = weights_pair
+    args = _Args()
+    args.basedir = str(tmp_path)
+    ck = tmp_path / "exp" / "checkpoints"
+    ck.mkdir(parents=True)
+    # the file the reference writes at nerf.ipynb:1290-1299
+    torch.save({'global_step': 1234,
+                'network_fn_state_dict': {k: torch.from_numpy(v) for k, v in sd_c.items()},
+                'network_fine_state_dict': {k: torch.from_numpy(v) for k, v in sd_f.items()},
+                'optimizer_state_dict': {}}, str(ck / "001234.tar"))
+    train_kw, test_kw, start, grad_vars, optimizer = N.create_nerf(args)
+    assert start == 1234 and grad_vars is None and optimizer is None
+    assert test_kw['perturb'] is False and test_kw['raw_noise_std'] == 0. and test_kw['ndc'] is False
+    assert train_kw['raw_noise_std'] == '1e0' and train_kw['network_fine'] is not None
+    g = load_golden("render_small")
+    H, W = int(g["H"]), int(g["W"])
+    poses = np.stack([synthetic.pose_spherical(30.0, -30.0, 4.0), synthetic.pose_spherical(75.0, -30.0, 4.0)])
+    test_kw.update(near=2., far=6.)
+    out_dir = tmp_path / "frames"
+    out_dir.mkdir()
+    rgbs, disps = N.render_path(torch.from_numpy(poses), (H, W, float(g["K"][0][0])), g["K"], 64, test_kw, savedir=str(out_dir))
+    assert rgbs.shape == (2, H, W, 3) and disps.shape == (2, H, W)
+    check_end_to_end(rgbs[0].reshape(-1, 3), g["rgb"].reshape(-1, 3))     # pose 0 is the golden frame's pose
+    assert sorted(p.name for p in out_dir.iterdir()) == ["000.png", "001.png"]
+    # metrics path: a frame against itself
+    rgbs2, _, avg = N.render_path(torch.from_numpy(poses[:1]), (H, W, float(g["K"][0][0])), g["K"], 64, test_kw,
+                                  gt_imgs=[rgbs[0]], calculate_metrics=True, metrics_include_lpips=False)
+    assert avg["avg_ssim"] > 0.9999 and avg["avg_mse"] < 1e-10
+    # render_factor halves the grid
+    r3, _ = N.render_path(torch.from_numpy(poses[:1]), (H, W, float(g["K"][0][0])), g["K"], 64, test_kw, render_factor=2)
+    assert r3.shape == (1, H // 2, W // 2, 3)
+    # training kwargs run the perturbed / noisy path with the package's own RNG
+    train_kw.update(near=2., far=6.)
+    rgb_t = N.render(H, W, g["K"], chunk=64, c2w=poses[0][:3, :4], **train_kw)[0]
+    assert torch.isfinite(rgb_t).all()
+
+
+def test_create_nerf_without_viewdirs(N, O, tmp_path):
+    """use_viewdirs=False: input_ch_views=0 and a 5-channel output_linear (nerf.ipynb:879-885)."""
+    args = _Args()
+    args.basedir, args.use_viewdirs, args.no_reload = str(tmp_path), False, True
+    train_kw, test_kw, *_ = N.create_nerf(args)
+    sd = synthetic.synthetic_state_dict(8, input_ch_views=0, use_viewdirs=False, output_ch=5)
+    sd_f = synthetic.perturbed_copy(sd, 9)
+    test_kw['network_fn'].load_state_dict(sd)
+    test_kw['network_fine'].load_state_dict(sd_f)
+    K, c2w, near, far = synthetic.lego_camera(16, 16)
+    test_kw.update(near=near, far=far)
+    use_viewdirs = test_kw.pop('use_viewdirs')
+    rgb, disp, acc, extras = N.render(16, 16, K, chunk=100, c2w=c2w, use_viewdirs=use_viewdirs, **test_kw)
+    onet_c = O.NeRF(8, 256, 63, 0, 5, (4,), False, sd)
+    onet_f = O.NeRF(8, 256, 63, 0, 5, (4,), False, sd_f)
+    oq = O.make_query_fn(O.get_embedder(10)[0], None)
+    want = O.render(16, 16, K, chunk=100, c2w=c2w, ndc=False, near=near, far=far, use_viewdirs=False,
+                    network_fn=onet_c, network_fine=onet_f, network_query_fn=oq, N_samples=16, N_importance=16,
+                    white_bkgd=True)
+    assert np.abs(cpu(extras["rgb0"]) - want[3]["rgb0"]).max() <= 1e-5
+    check_end_to_end(cpu(rgb).reshape(-1, 3), want[0].reshape(-1, 3))

@@ -217,3 +217,30 @@ def test_ray_packing():
     n = load_golden("render_rays_ndc")
     packed, _ = O.pack_rays(756, 1008, n["K"], c2w=n["c2w"], ndc=True, near=0., far=1., use_viewdirs=True)
     np.testing.assert_allclose(packed[n["pix"]], n["rays"], rtol=0, atol=1e-6)
+
+
+def test_ray_packing_all_camera_modes():
+    """Oracle pack_rays vs the record the reference's own render() hands to batchify_rays."""
+    g = load_golden("ray_packing")
+    H, W = int(g["H"]), int(g["W"])
+    cases = {
+        "lego": dict(K=g["K_lego"], c2w=g["c2w"], ndc=False, near=2., far=6., use_viewdirs=True),
+        "static": dict(K=g["K_lego"], c2w=g["c2w"], ndc=False, near=2., far=6., use_viewdirs=True,
+                       c2w_staticcam=g["c2w_static"]),
+        "noview": dict(K=g["K_lego"], c2w=g["c2w"], ndc=False, near=2., far=6., use_viewdirs=False),
+        "ndc": dict(K=g["K_fern"], c2w=g["c2w_fern"], ndc=True, near=0., far=1., use_viewdirs=True),
+    }
+    for name, kw in cases.items():
+        K = kw.pop("K")
+        packed, sh = O.pack_rays(H, W, K, **kw)
+        assert packed.shape == g[name].shape and sh == (H, W, 3), name
+        np.testing.assert_allclose(packed, g[name], rtol=0, atol=2e-6, err_msg=name)
+
+
+def test_image_metrics():
+    g = load_golden("metrics")
+    m = O.calculate_metrics(g["img1"], g["img2"])
+    assert abs(m["mse"] - float(g["mse"])) <= 1e-8
+    assert abs(m["psnr"] - float(g["psnr"])) <= 1e-4
+    assert abs(m["ssim"] - float(g["ssim"])) <= 2e-5      # sigma = E[x^2]-mu^2 cancels; c2 = 9e-4 amplifies fp32 rounding
+    assert abs(O.calculate_ssim(g["img1"], g["img1"]) - float(g["ssim_same"])) <= 2e-6
