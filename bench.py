@@ -51,6 +51,8 @@ def parse():
     p.add_argument("--chunk", type=int, default=32768)
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--force-collective", action="store_true",
+                   help="under torch.distributed.run with one rank: still create the RCCL group and gather")
     return p.parse_args()
 
 
@@ -104,7 +106,8 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or (args.force_collective and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
@@ -136,12 +139,12 @@ def main():
     def step():
         ret = N.batchify_rays(shard, args.chunk, **kw)
         local_out = {k: ret[k] for k in ("rgb_map", "disp_map", "acc_map")}
-        if world > 1:
-            return N.gather_frame(local_out, n_total)
+        if use_dist:
+            return N.gather_frame(local_out, n_total, force_collective=True)
         return local_out
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -159,7 +162,7 @@ def main():
     ctx.profile_enable(False)
     mlp_ms, mlp_launches, mlp_points = ctx.profile_read(reset=True)
     t = torch.tensor([dt, mlp_ms, float(mlp_points), float(mlp_launches)], device="cuda", dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -209,7 +212,7 @@ def main():
                 e0 = np.abs(frame_rgb0(N, shard, idx[:n_used], kw) - ref["rgb0"]).max()
                 out["parity"]["rgb0_linf"] = float(e0)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

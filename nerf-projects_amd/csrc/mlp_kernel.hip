@@ -155,8 +155,10 @@ __device__ __forceinline__ void run_steps(Pipe& p, Frag16& cur, const f32x4* fr,
             // keep the step's 15 trailing MFMAs above the barrier: the reads issued before them have
             // returned by then, so the counters the barrier drains (vmcnt, lgkmcnt) are already empty
             __builtin_amdgcn_sched_barrier(0);
+#ifndef NERF_ABLATE_BARRIER
             __syncthreads();
-            const int nx = p.c + 2 < p.n ? p.c + 2 : p.n - 1;   // past the end: reload the last chunk (harmless)
+#endif
+            const int nx = p.c + 2 < p.n ? p.c + 2 : p.c + 2 - p.n;   // wraps into the next tile's stream
             prefetch_chunk(p, nx, ring_next(p.b, 2));
 #if NERF_MLP_SYNC_VARIANT == 0
             __builtin_amdgcn_sched_barrier(0);
@@ -216,7 +218,11 @@ __device__ __forceinline__ void activate(f32x16 (&dst)[8], const f32x16 (&src)[8
 #pragma unroll
     for (int t = 0; t < N; ++t)
 #pragma unroll
+#ifdef NERF_ABLATE_RELU
+        for (int r = 0; r < 16; ++r) dst[t][r] = (r == 0 && t == 0) ? src[t][r] : dst[t][r];
+#else
         for (int r = 0; r < 16; ++r) dst[t][r] = RELU ? fmaxf(src[t][r], 0.0f) : src[t][r];
+#endif
 }
 
 // ---- inputs -----------------------------------------------------------------------------
@@ -236,7 +242,11 @@ __device__ __forceinline__ void encode_point(const float (&p)[3], const float (&
 #pragma unroll
     for (int s = 0; s < 30; ++s) {
         float sn, cs;
+#ifdef NERF_ABLATE_PE
+        sn = p[s % 3] * (float)(1 << (s / 3)); cs = sn + 1.0f;
+#else
         sincosf(p[s % 3] * (float)(1 << (s / 3)), &sn, &cs);
+#endif
         const float v = h ? cs : sn;
         if (s < 16) x0[s] = v; else x1[s - 16] = v;
     }
@@ -246,7 +256,11 @@ __device__ __forceinline__ void encode_point(const float (&p)[3], const float (&
 #pragma unroll
         for (int t = 0; t < 12; ++t) {
             float sn, cs;
+#ifdef NERF_ABLATE_PE
+            sn = d[t % 3] * (float)(1 << (t / 3)); cs = sn + 1.0f;
+#else
             sincosf(d[t % 3] * (float)(1 << (t / 3)), &sn, &cs);
+#endif
             dd[t] = h ? cs : sn;
         }
         dd[12] = h ? d[2] : d[0];
@@ -317,17 +331,23 @@ void nerf_mlp_kernel(const MlpLaunch a) {
     prefetch_chunk(pipe, 0, 0);
     prefetch_chunk(pipe, a.n_chunks > 1 ? 1 : 0, 1);
     for (int i = threadIdx.x; i < a.n_bias_tiles * kBiasTileFloats; i += 256) bias_lds[i] = a.bias[i];
+    __syncthreads();   // chunks 0 and 1 and the bias block are in LDS
+    Frag16 cur = read_frags(ring_frags(pipe, 0), 0);
 
-    const int64_t tile0 = (int64_t)blockIdx.x * kPointsPerGroup + wave * kPointsPerWave;
+    // Persistent workgroup: one per CU, walking 128-point tiles with stride gridDim.x. The weight
+    // ring never drains between tiles: the tail of one tile's stream prefetches the head of the
+    // next (prefetch wraps modulo n_chunks), and the bias block stays in LDS.
+    const int64_t n_tiles = (a.n_points + kPointsPerGroup - 1) / kPointsPerGroup;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    pipe.c = 0;
+    const int64_t tile0 = tile * kPointsPerGroup + wave * kPointsPerWave;
     const int64_t pt_raw = tile0 + (lane & 31);
     const int64_t pt = pt_raw < a.n_points ? pt_raw : a.n_points - 1;   // clamp: padded lanes recompute the last point
 
     f32x16 x0, x1, dd;
     load_inputs<MODE>(a, pt, h, x0, x1, dd);
-    __syncthreads();   // chunks 0 and 1 and the bias block are in LDS
 
     f32x16 hid[8], acc[8];
-    Frag16 cur = read_frags(ring_frags(pipe, 0), 0);
 
     // layer 0: gamma(xyz) -> W (nerf.py:70-73)
     load_bias<8>(acc, bias_lds, 0, h);
@@ -385,21 +405,30 @@ void nerf_mlp_kernel(const MlpLaunch a) {
             }
         }
     }
-    // the ring's trailing (clamped) prefetches must land before this workgroup's LDS is released
+    }   // tile loop
+    // the ring's trailing prefetches must land before this workgroup's LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 hipError_t launch_mlp(const MlpLaunch& a, int mode, hipStream_t s) {
     if (a.n_points <= 0) return hipSuccess;
-    const int64_t groups = (a.n_points + kPointsPerGroup - 1) / kPointsPerGroup;
-    if (groups > 0x7fffffffLL) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)groups), block(256);
-    const size_t lds = kBiasLdsBytes + kRing * kChunkBytes;
-    // 112 KiB of dynamic LDS is above the 64 KiB default cap: raise it once per device and mode
-    static bool raised[64][3] = {};
+    const int64_t tiles = (a.n_points + kPointsPerGroup - 1) / kPointsPerGroup;
+    // persistent grid: the kernel's 112 KiB of LDS and 512 registers per lane admit exactly one
+    // workgroup per CU, so one workgroup per CU walks the tiles
+    static int n_cu[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!n_cu[dev]) {
+        e = hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        if (n_cu[dev] <= 0) n_cu[dev] = 256;
+    }
+    const dim3 grid((unsigned)(tiles < n_cu[dev] ? tiles : n_cu[dev])), block(256);
+    const size_t lds = kBiasLdsBytes + kRing * kChunkBytes;
+    // 112 KiB of dynamic LDS is above the 64 KiB default cap: raise it once per device and mode
+    static bool raised[64][3] = {};
     if (mode < 0 || mode > 2) return hipErrorInvalidValue;
     if (dev < 64 && !raised[dev][mode]) {
         const void* fn = mode == kInputEmbedded ? (const void*)nerf_mlp_kernel<kInputEmbedded>

@@ -19,12 +19,13 @@ def shard_bounds(n, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_frame(local, n_total, group=None, dst=0):
+def gather_frame(local, n_total, group=None, dst=0, force_collective=False):
     """Gather per-ray outputs ``{name: [n_local, ...]}`` of every rank to ``dst``.
 
     All fields are packed into one ``[n_max, C]`` fp32 buffer per rank (padded to the
     largest shard so a plain ``gather`` applies): one collective per frame. Returns the
-    ``{name: [n_total, ...]}`` dict on ``dst`` and ``None`` elsewhere.
+    ``{name: [n_total, ...]}`` dict on ``dst`` and ``None`` elsewhere. ``force_collective``
+    issues the gather even in a one-rank group (used to exercise the RCCL path on one GPU).
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -39,7 +40,7 @@ def gather_frame(local, n_total, group=None, dst=0):
     for k, w in zip(names, widths):
         buf[:n_local, col:col + w] = local[k].reshape(n_local, w)
         col += w
-    if world == 1:
+    if world == 1 and not force_collective:
         parts = [buf]
     else:
         dst_global = dist.get_global_rank(group, dst) if group is not None else dst

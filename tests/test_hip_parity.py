@@ -450,3 +450,27 @@ def test_create_nerf_without_viewdirs(N, O, tmp_path):
                     white_bkgd=True)
     assert np.abs(cpu(extras["rgb0"]) - want[3]["rgb0"]).max() <= 1e-5
     check_end_to_end(cpu(rgb).reshape(-1, 3), want[0].reshape(-1, 3))
+
+
+def test_bench_under_torchrun_with_rccl_group(N):
+    """bench.py launched the way the driver launches the N>1 case, with one rank: creates the RCCL
+    process group on the GPU, runs the frame-end gather through it and prints the contract line."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1",
+           "--warmup", "0", "--no-cpu-baseline", "--force-collective", "--workload", "lego_400x400_64c"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["metric"] == "ray_samples_per_sec" and d["n_gpus"] == 1 and d["value"] > 1e7
+    assert d["config"]["workload"] == "lego_400x400_64c" and d["roofline"]["frac"] > 0.3
