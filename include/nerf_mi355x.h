@@ -194,6 +194,40 @@ int nerf_generate_rays(nerf_ctx* ctx, const nerf_camera* cam, int64_t first_pixe
 int nerf_image_metrics(nerf_ctx* ctx, const float* img1 /*[dev] [H,W,3]*/, const float* img2 /*[dev]*/,
                        int H, int W, float max_val, float* out /*[dev] [2]*/, void* stream);
 
+/* Training step -----------------------------------------------------
+ * One iteration of the reference's training loop body (nerf.ipynb:1258-1282) for a batch of rays:
+ *   render(rays, retraw=True, **render_kwargs_train) -> loss = img2mse(rgb, target) [+ img2mse(rgb0,
+ *   target) when N_importance > 0] -> loss.backward() -> torch.optim.Adam step,
+ * on the master fp32 copy of the weights that nerf_load_weights keeps on the device. Afterwards the
+ * inference entry points see the updated weights. The caller owns the RNG (t_rand, u_rand, noise*, as in
+ * nerf_render_args), the ray batching and the learning-rate schedule (nerf.ipynb:1278-1282).
+ */
+typedef struct nerf_train_args {
+    const float* rays;          /* [dev] [N, 8|11] as render() packs them                       */
+    const float* target;        /* [dev] [N,3] target_s                                         */
+    int64_t n_rays;
+    int32_t ray_stride;
+    int32_t N_samples, N_importance;
+    int32_t slot_coarse, slot_fine;     /* a distinct fine network is required when N_importance > 0 */
+    int32_t lindisp, white_bkgd, perturb;
+    const float* t_rand;        /* [dev] [N,S_c]      */
+    const float* u_rand;        /* [dev] [N,S_i]      */
+    const float* noise0;        /* [dev] [N,S_c]      */
+    const float* noise;         /* [dev] [N,S_c+S_i]  */
+    float lr, beta1, beta2, eps;        /* Adam; the reference uses betas (0.9, 0.999), eps 1e-8     */
+    int32_t step;               /* 1-based optimizer step count (bias correction)               */
+    int32_t apply_update;       /* 0: compute loss and gradients only                           */
+    float* loss;                /* [dev] [2]: img_loss of the last pass, img_loss0 of the coarse pass */
+    float* rgb_map;             /* [dev] [N,3] optional                                         */
+    float* rgb0;                /* [dev] [N,3] optional                                         */
+    void* stream;
+} nerf_train_args;
+
+int nerf_train_step(nerf_ctx* ctx, const nerf_train_args* args);
+/* Current master weights / last gradients of a slot, copied to host tensors in nerf_load_weights order. */
+int nerf_get_weights(nerf_ctx* ctx, int slot, float* const* tensors /*[host]*/, int n_tensors);
+int nerf_get_gradients(nerf_ctx* ctx, int slot, float* const* tensors /*[host]*/, int n_tensors);
+
 /* Measurement hooks ------------------------------------------------------------------
  * Accumulated device time of the dominant kernel (the fused encode+MLP kernel),
  * measured with HIP events recorded on the launch stream around every launch while

@@ -6,7 +6,7 @@ Importing the package never touches the GPU; the first call that needs it loads
 ``libnerf_mi355x.so`` and raises if the library or a gfx950 device is missing.
 """
 from . import synthetic  # noqa: F401
-from .host import (NeRF, NetworkQuery, batchify, batchify_rays, calculate_lpips, calculate_metrics,  # noqa: F401
+from .host import (Adam, NeRF, NetworkQuery, train_on_batch, batchify, batchify_rays, calculate_lpips, calculate_metrics,  # noqa: F401
                    calculate_ssim, create_nerf, generate_rays, get_context, get_embedder, get_rays, get_rays_np,
                    img2mse, load_checkpoint, make_network_query_fn, mse2psnr, ndc_rays, pack_rays, raw2outputs,
                    render, render_path, render_rays, run_network, sample_pdf, to8b, write_png)

@@ -16,7 +16,8 @@ EXPORTS = (
     "nerf_last_error", "nerf_version", "nerf_device_count", "nerf_ctx_create", "nerf_ctx_destroy",
     "nerf_load_weights", "nerf_num_weight_tensors", "nerf_embed", "nerf_mlp_forward", "nerf_run_network",
     "nerf_raw2outputs", "nerf_sample_pdf", "nerf_render_rays", "nerf_profile_enable", "nerf_profile_read",
-    "nerf_workspace_bytes", "nerf_generate_rays", "nerf_image_metrics",
+    "nerf_workspace_bytes", "nerf_generate_rays", "nerf_image_metrics", "nerf_train_step", "nerf_get_weights",
+    "nerf_get_gradients",
 )
 
 
@@ -38,6 +39,15 @@ class RenderArgs(C.Structure):
                 ("disp0", _FP), ("acc0", _FP), ("z_std", _FP), ("z_vals_coarse", _FP),
                 ("weights_coarse", _FP), ("z_samples", _FP), ("z_vals_fine", _FP), ("weights_fine", _FP),
                 ("depth_map", _FP), ("z_vals_fine_in", _FP), ("stream", C.c_void_p)]
+
+
+class TrainArgs(C.Structure):
+    _fields_ = [("rays", _FP), ("target", _FP), ("n_rays", C.c_int64), ("ray_stride", C.c_int32),
+                ("N_samples", C.c_int32), ("N_importance", C.c_int32), ("slot_coarse", C.c_int32),
+                ("slot_fine", C.c_int32), ("lindisp", C.c_int32), ("white_bkgd", C.c_int32), ("perturb", C.c_int32),
+                ("t_rand", _FP), ("u_rand", _FP), ("noise0", _FP), ("noise", _FP), ("lr", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int32),
+                ("apply_update", C.c_int32), ("loss", _FP), ("rgb_map", _FP), ("rgb0", _FP), ("stream", C.c_void_p)]
 
 
 class Camera(C.Structure):
@@ -99,6 +109,12 @@ def load():
     lib.nerf_generate_rays.argtypes = [vp, C.POINTER(Camera), i64, i64, vp, vp]
     lib.nerf_image_metrics.restype = i32
     lib.nerf_image_metrics.argtypes = [vp, vp, vp, i32, i32, C.c_float, vp, vp]
+    lib.nerf_train_step.restype = i32
+    lib.nerf_train_step.argtypes = [vp, C.POINTER(TrainArgs)]
+    lib.nerf_get_weights.restype = i32
+    lib.nerf_get_weights.argtypes = [vp, i32, C.POINTER(vp), i32]
+    lib.nerf_get_gradients.restype = i32
+    lib.nerf_get_gradients.argtypes = [vp, i32, C.POINTER(vp), i32]
     lib.nerf_workspace_bytes.restype = i64
     lib.nerf_workspace_bytes.argtypes = [vp]
     _lib = lib

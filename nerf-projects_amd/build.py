@@ -13,8 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnerf_mi355x.so")
-SOURCES = ["api.cpp", "pack_weights.cpp", "mlp_kernel.hip", "ray_kernels.hip"]
-HEADERS = [os.path.join(CSRC, "nerf_internal.h"), os.path.join(ROOT, "include", "nerf_mi355x.h")]
+SOURCES = ["api.cpp", "train_api.cpp", "pack_weights.cpp", "mlp_kernel.hip", "ray_kernels.hip", "train_kernels.hip"]
+HEADERS = [os.path.join(CSRC, "nerf_internal.h"), os.path.join(CSRC, "ctx_internal.h"),
+           os.path.join(ROOT, "include", "nerf_mi355x.h")]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
     "-ffp-contract=off",          # PyTorch's op boundaries are rounding boundaries; fmaf is explicit where wanted

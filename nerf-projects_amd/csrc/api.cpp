@@ -23,78 +23,11 @@ void set_error(const char* fmt, ...) {
 
 }  // namespace nerf
 
+#include "ctx_internal.h"
+
 using namespace nerf;
 
-#define HIP_TRY(expr)                                                                        \
-    do {                                                                                     \
-        hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess) {                                                              \
-            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return NERF_E_HIP;                                                               \
-        }                                                                                    \
-    } while (0)
-
-struct nerf_ctx {
-    int device = 0;
-    PackedNet nets[NERF_NUM_SLOTS];
-    char* ws = nullptr;          // workspace arena
-    size_t ws_bytes = 0;
-    bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per MLP launch
-    std::vector<hipEvent_t> pool;
-    int64_t prof_points = 0;
-    double prof_ms = 0.0;
-    int64_t prof_launches = 0;
-};
-
 namespace {
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-
-int ensure_workspace(nerf_ctx* c, size_t bytes) {
-    if (bytes <= c->ws_bytes) return NERF_OK;
-    // growing is rare (first call at a given chunk size); it synchronises the device
-    if (c->ws) {
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(c->ws));
-        c->ws = nullptr;
-        c->ws_bytes = 0;
-    }
-    const size_t want = bytes + bytes / 8;
-    hipError_t e = hipMalloc((void**)&c->ws, want);
-    if (e != hipSuccess) {
-        set_error("hipMalloc(%zu) for the render workspace failed: %s", want, hipGetErrorString(e));
-        return NERF_E_NOMEM;
-    }
-    c->ws_bytes = want;
-    return NERF_OK;
-}
-
-struct Arena {
-    char* base;
-    size_t off = 0;
-    explicit Arena(char* b) : base(b) {}
-    float* take(size_t n_floats) {
-        float* p = (float*)(base + off);
-        off += (n_floats * sizeof(float) + 255) & ~(size_t)255;
-        return p;
-    }
-};
-size_t arena_bytes(std::initializer_list<size_t> float_counts) {
-    size_t t = 0;
-    for (size_t n : float_counts) t += (n * sizeof(float) + 255) & ~(size_t)255;
-    return t;
-}
 
 int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net, int mode, hipStream_t s) {
     a.stream = net.d_stream;
@@ -126,6 +59,41 @@ int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net, int mode, hipStream
         c->prof_points += a.n_points;
     }
     return NERF_OK;
+}
+
+void free_net(PackedNet& n) {
+    for (void* p : {(void*)n.d_stream, (void*)n.d_bias, (void*)n.d_params, (void*)n.train.d_grad, (void*)n.train.d_m,
+                    (void*)n.train.d_v, (void*)n.train.d_wt, (void*)n.train.d_stream_table,
+                    (void*)n.train.d_bias_table})
+        if (p) (void)hipFree(p);
+    n = PackedNet{};
+}
+
+// shapes of the state_dict tensors in the order nerf_load_weights receives them
+std::vector<LinearDesc> describe_linears(const nerf_arch& a, uint32_t skip_in_mask) {
+    std::vector<LinearDesc> L;
+    size_t off = 0;
+    auto add = [&](int out, int in) {
+        LinearDesc d;
+        d.out = out;
+        d.in = in;
+        d.w_off = off;
+        off += (size_t)out * in;
+        d.b_off = off;
+        off += (size_t)out;
+        L.push_back(d);
+    };
+    for (int i = 0; i < a.D; ++i)
+        add(a.W, i == 0 ? a.input_ch : (((skip_in_mask >> i) & 1) ? a.W + a.input_ch : a.W));
+    add(a.W / 2, a.input_ch_views + a.W);
+    if (a.use_viewdirs) {
+        add(a.W, a.W);
+        add(1, a.W);
+        add(3, a.W / 2);
+    } else {
+        add(a.output_ch, a.W);
+    }
+    return L;
 }
 
 const PackedNet* get_net(nerf_ctx* c, int slot) {
@@ -196,10 +164,7 @@ void nerf_ctx_destroy(nerf_ctx* c) {
     if (!c) return;
     DeviceGuard g(c->device);
     (void)hipDeviceSynchronize();
-    for (auto& n : c->nets) {
-        if (n.d_stream) (void)hipFree(n.d_stream);
-        if (n.d_bias) (void)hipFree(n.d_bias);
-    }
+    for (auto& n : c->nets) free_net(n);
     if (c->ws) (void)hipFree(c->ws);
     for (auto& p : c->events) {
         (void)hipEventDestroy(p.first);
@@ -227,9 +192,49 @@ int nerf_load_weights(nerf_ctx* c, int slot, const nerf_arch* arch, const float*
     PackedNet& net = c->nets[slot];
     // the previous stream of this slot may still be in use by enqueued work
     hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess && net.d_stream) e = hipFree(net.d_stream);
-    if (e == hipSuccess && net.d_bias) e = hipFree(net.d_bias);
-    net = PackedNet{};
+    free_net(net);
+    // flat master copy + the index tables that map the packed layouts back to it (for training)
+    net.linears = describe_linears(*arch, mask);
+    std::vector<float> flat, fake;
+    {
+        std::vector<const float*> fake_ptrs;
+        size_t total = 0;
+        for (const LinearDesc& d : net.linears) total += (size_t)d.out * d.in + d.out;
+        flat.resize(total);
+        fake.resize(total);
+        for (size_t i = 0; i < total; ++i) fake[i] = (float)(i + 1);   // exact: total < 2^24
+        if (total >= (1u << 24)) {
+            free(hs);
+            free(hb);
+            set_error("model too large for the index tables (%zu parameters)", total);
+            return NERF_E_INVALID;
+        }
+        for (size_t k = 0; k < net.linears.size(); ++k) {
+            const LinearDesc& d = net.linears[k];
+            memcpy(flat.data() + d.w_off, tensors[2 * k], (size_t)d.out * d.in * sizeof(float));
+            memcpy(flat.data() + d.b_off, tensors[2 * k + 1], (size_t)d.out * sizeof(float));
+            fake_ptrs.push_back(fake.data() + d.w_off);
+            fake_ptrs.push_back(fake.data() + d.b_off);
+        }
+        float *ts = nullptr, *tb = nullptr;
+        int tnc = 0, tnb = 0, toc = 0;
+        uint32_t tm = 0;
+        rc = pack_weights(*arch, fake_ptrs.data(), n_tensors, &ts, &tnc, &tb, &tnb, &tm, &toc);
+        if (rc != NERF_OK) {
+            free(hs);
+            free(hb);
+            return rc;
+        }
+        net.stream_table.resize((size_t)tnc * kChunkFloats);
+        net.bias_table.resize((size_t)tnb * kBiasTileFloats);
+        for (size_t i = 0; i < net.stream_table.size(); ++i) net.stream_table[i] = (int)ts[i] - 1;
+        for (size_t i = 0; i < net.bias_table.size(); ++i) net.bias_table[i] = (int)tb[i] - 1;
+        free(ts);
+        free(tb);
+        net.n_params = total;
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&net.d_params, net.n_params * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(net.d_params, flat.data(), net.n_params * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&net.d_stream, (size_t)nc * kChunkBytes);
     if (e == hipSuccess) e = hipMalloc((void**)&net.d_bias, (size_t)nbt * kBiasTileFloats * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(net.d_stream, hs, (size_t)nc * kChunkBytes, hipMemcpyHostToDevice);

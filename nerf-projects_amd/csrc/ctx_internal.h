@@ -1,0 +1,81 @@
+// Context definition and small host helpers shared by api.cpp and train_api.cpp.
+#pragma once
+#include <cstddef>
+#include <initializer_list>
+#include <utility>
+#include <vector>
+
+#include "nerf_internal.h"
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            nerf::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return NERF_E_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+struct nerf_ctx {
+    int device = 0;
+    nerf::PackedNet nets[NERF_NUM_SLOTS];
+    char* ws = nullptr;          // workspace arena
+    size_t ws_bytes = 0;
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per MLP launch
+    std::vector<hipEvent_t> pool;
+    int64_t prof_points = 0;
+    double prof_ms = 0.0;
+    int64_t prof_launches = 0;
+};
+
+namespace nerf {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+inline int ensure_workspace(nerf_ctx* c, size_t bytes) {
+    if (bytes <= c->ws_bytes) return NERF_OK;
+    // growing is rare (first call at a given chunk size); it synchronises the device
+    if (c->ws) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(c->ws));
+        c->ws = nullptr;
+        c->ws_bytes = 0;
+    }
+    const size_t want = bytes + bytes / 8;
+    hipError_t e = hipMalloc((void**)&c->ws, want);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu) for the render workspace failed: %s", want, hipGetErrorString(e));
+        return NERF_E_NOMEM;
+    }
+    c->ws_bytes = want;
+    return NERF_OK;
+}
+
+struct Arena {
+    char* base;
+    size_t off = 0;
+    explicit Arena(char* b) : base(b) {}
+    float* take(size_t n_floats) {
+        float* p = (float*)(base + off);
+        off += (n_floats * sizeof(float) + 255) & ~(size_t)255;
+        return p;
+    }
+};
+inline size_t arena_bytes(std::initializer_list<size_t> float_counts) {
+    size_t t = 0;
+    for (size_t n : float_counts) t += (n * sizeof(float) + 255) & ~(size_t)255;
+    return t;
+}
+
+}  // namespace nerf

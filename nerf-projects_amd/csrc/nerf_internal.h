@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "nerf_mi355x.h"
 
 namespace nerf {
@@ -23,9 +25,32 @@ constexpr int kPointsPerWave = 32;
 constexpr int kWavesPerGroup = 4;
 constexpr int kPointsPerGroup = kPointsPerWave * kWavesPerGroup;
 
+// one nn.Linear inside the flat parameter buffer (state_dict order: weight [out,in] then bias [out])
+struct LinearDesc {
+    int out = 0, in = 0;
+    size_t w_off = 0, b_off = 0;
+};
+
+// optimiser state, created on the first training step of a slot
+struct TrainState {
+    bool ready = false;
+    float* d_grad = nullptr;     // n_params
+    float* d_m = nullptr;        // Adam exp_avg
+    float* d_v = nullptr;        // Adam exp_avg_sq
+    float* d_wt = nullptr;       // every weight transposed ([in,out]) at the same w_off: B operand of the forward GEMMs
+    int* d_stream_table = nullptr;   // fused-stream element -> index into params (or -1)
+    int* d_bias_table = nullptr;
+    bool grads_valid = false;
+};
+
 struct PackedNet {
     nerf_arch arch{};
     bool loaded = false;
+    float* d_params = nullptr;   // flat master copy of the state dict (fp32)
+    size_t n_params = 0;
+    std::vector<LinearDesc> linears;   // pts_linears[0..D-1], views, then feature, alpha, rgb | output
+    std::vector<int> stream_table, bias_table;
+    TrainState train;
     float* d_stream = nullptr;   // n_chunks * kChunkFloats
     float* d_bias = nullptr;     // n_bias_tiles * kBiasTileFloats
     int n_chunks = 0;
@@ -84,6 +109,38 @@ hipError_t launch_sample_pdf(const float* bins, const float* weights, int w_ld, 
 hipError_t launch_raygen(const nerf_camera& cam, int64_t first, int64_t n, float* rays, hipStream_t s);
 hipError_t launch_image_metrics(const float* a, const float* b, int H, int W, float max_val, float* tmp,
                                 double* partial, float* out, hipStream_t s);
+
+// ---- training (train_kernels.hip) -------------------------------------------------------------------
+struct GemmRows {      // C[M,N] = A[M,K] B[K,N]  (+bias) (ReLU) (C *= mask > 0) (C += old C)
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    int64_t M; int N, K;
+    const float* bias;
+    int relu;
+    const float* mask; int ldm;
+    int accumulate;
+};
+struct GemmTN {        // part[slice][Mo, No(+1)] = sum_p A[p,Mo]^T [B[p,No] | 1]
+    const float* A; int lda;
+    const float* B; int ldb;
+    int64_t P; int Mo, No;
+    int ones;
+    int64_t pts_per_slice;
+    float* part;
+};
+hipError_t launch_gemm_rows(const GemmRows& g, hipStream_t s);
+hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, float* db, hipStream_t s);
+hipError_t launch_embed_train(const float* rays, int ray_ld, const float* z, int64_t P, int S, int Lx, int Lv,
+                              float* xcat, int ldx, float* vcat, int ldv, int voff, hipStream_t s);
+hipError_t launch_mse(const float* x, const float* t, int64_t n, float* grad, double* part, float* loss, hipStream_t s);
+hipError_t launch_composite_bwd(const float* raw, int C, const float* z, const float* rays_d, int d_ld,
+                                const float* noise, int white_bkgd, int64_t N, int S, const float* g_rgb,
+                                float* d_raw, hipStream_t s);
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                       int step, hipStream_t s);
+hipError_t launch_transpose(const float* src, int rows, int cols, float* dst, hipStream_t s);
+hipError_t launch_gather(const float* params, const int* table, int64_t n, float* out, hipStream_t s);
 
 void set_error(const char* fmt, ...);
 

@@ -1,0 +1,409 @@
+// Training step behind the C ABI: the body of the reference's training
+// iteration, nerf.ipynb:1258-1282 -
+//     render(rays=batch_rays, retraw=True, **render_kwargs_train) -> img2mse(rgb, target) [+ img2mse(rgb0, target)]
+//     -> loss.backward() -> Adam step
+// for one batch of rays, entirely on the device. The caller owns the RNG (t_rand / u_rand / noise),
+// the ray batching and the learning-rate schedule.
+#include <cmath>
+#include <cstring>
+
+#include "ctx_internal.h"
+
+using namespace nerf;
+
+namespace {
+
+int ensure_train_state(nerf_ctx* c, PackedNet& net) {
+    TrainState& t = net.train;
+    if (t.ready) return NERF_OK;
+    const size_t nb = net.n_params * sizeof(float);
+    HIP_TRY(hipMalloc((void**)&t.d_grad, nb));
+    HIP_TRY(hipMalloc((void**)&t.d_m, nb));
+    HIP_TRY(hipMalloc((void**)&t.d_v, nb));
+    HIP_TRY(hipMalloc((void**)&t.d_wt, nb));
+    HIP_TRY(hipMemset(t.d_grad, 0, nb));
+    HIP_TRY(hipMemset(t.d_m, 0, nb));
+    HIP_TRY(hipMemset(t.d_v, 0, nb));
+    HIP_TRY(hipMalloc((void**)&t.d_stream_table, net.stream_table.size() * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&t.d_bias_table, net.bias_table.size() * sizeof(int)));
+    HIP_TRY(hipMemcpy(t.d_stream_table, net.stream_table.data(), net.stream_table.size() * sizeof(int),
+                      hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.d_bias_table, net.bias_table.data(), net.bias_table.size() * sizeof(int),
+                      hipMemcpyHostToDevice));
+    t.ready = true;
+    return NERF_OK;
+}
+
+// W^T copies for the forward GEMMs and the fused inference stream, from the master parameters
+int refresh_derived(PackedNet& net, hipStream_t s) {
+    for (const LinearDesc& d : net.linears)
+        HIP_TRY(launch_transpose(net.d_params + d.w_off, d.out, d.in, net.train.d_wt + d.w_off, s));
+    HIP_TRY(launch_gather(net.d_params, net.train.d_stream_table, (int64_t)net.stream_table.size(), net.d_stream, s));
+    HIP_TRY(launch_gather(net.d_params, net.train.d_bias_table, (int64_t)net.bias_table.size(), net.d_bias, s));
+    return NERF_OK;
+}
+
+struct Pass {              // one network evaluated at P = N*S points with everything autograd would keep
+    const PackedNet* net;
+    int64_t N, P;
+    int S;
+    std::vector<float*> in;      // input of trunk layer i ([P, in_i], row stride in_ld[i])
+    std::vector<int> in_ld;
+    std::vector<float*> h;       // output of trunk layer i (post ReLU), row stride h_ld[i]
+    std::vector<int> h_ld;
+    float *vcat = nullptr, *hv = nullptr, *raw = nullptr, *d_raw = nullptr;
+    float *g_a = nullptr, *g_b = nullptr, *g_hv = nullptr;   // gradient scratch
+    int vcat_ld = 0, C = 4;
+};
+
+size_t pass_floats(const PackedNet& net, int64_t P) {
+    const nerf_arch& a = net.arch;
+    size_t f = (size_t)P * a.input_ch;
+    for (int i = 0; i < a.D; ++i) f += (size_t)P * (a.W + a.input_ch);
+    f += (size_t)P * (a.W + a.input_ch_views) + (size_t)P * (a.W / 2);
+    f += (size_t)P * 8 * 2;                     // raw, d_raw (<= 8 channels budgeted... out_ch <= 32 handled below)
+    f += (size_t)P * 2 * (net.out_ch > 8 ? net.out_ch : 0);
+    f += (size_t)P * a.W * 2 + (size_t)P * (a.W / 2);
+    return f + 64 * 32;
+}
+
+void carve_pass(Arena& ar, Pass& ps) {
+    const PackedNet& net = *ps.net;
+    const nerf_arch& a = net.arch;
+    const int64_t P = ps.P;
+    ps.C = net.out_ch;
+    float* E = ar.take((size_t)P * a.input_ch);
+    ps.in.assign(a.D, nullptr);
+    ps.in_ld.assign(a.D, 0);
+    ps.h.assign(a.D, nullptr);
+    ps.h_ld.assign(a.D, 0);
+    ps.in[0] = E;
+    ps.in_ld[0] = a.input_ch;
+    for (int i = 0; i < a.D; ++i) {
+        const bool next_cat = (i + 1 < a.D) && ((net.skip_in_mask >> (i + 1)) & 1);
+        if (next_cat) {
+            float* cat = ar.take((size_t)P * (a.W + a.input_ch));   // [gamma(x) | h_i] (nerf.py:79-80)
+            ps.h[i] = cat + a.input_ch;
+            ps.h_ld[i] = a.W + a.input_ch;
+            ps.in[i + 1] = cat;
+            ps.in_ld[i + 1] = a.W + a.input_ch;
+        } else {
+            ps.h[i] = ar.take((size_t)P * a.W);
+            ps.h_ld[i] = a.W;
+            if (i + 1 < a.D) {
+                ps.in[i + 1] = ps.h[i];
+                ps.in_ld[i + 1] = a.W;
+            }
+        }
+    }
+    if (a.use_viewdirs) {
+        ps.vcat_ld = a.W + a.input_ch_views;
+        ps.vcat = ar.take((size_t)P * ps.vcat_ld);                    // [feature | gamma(dir)] (nerf.py:93)
+        ps.hv = ar.take((size_t)P * (a.W / 2));
+    }
+    ps.raw = ar.take((size_t)P * ps.C);
+    ps.d_raw = ar.take((size_t)P * ps.C);
+    ps.g_a = ar.take((size_t)P * a.W);
+    ps.g_b = ar.take((size_t)P * a.W);
+    ps.g_hv = ar.take((size_t)P * (a.W / 2));
+}
+
+int forward_pass(Pass& ps, const float* rays, int ray_ld, const float* z, hipStream_t s) {
+    const PackedNet& net = *ps.net;
+    const nerf_arch& a = net.arch;
+    const float* wt = net.train.d_wt;
+    const float* prm = net.d_params;
+    const int Lx = (a.input_ch - 3) / 6, Lv = a.use_viewdirs ? (a.input_ch_views - 3) / 6 : 0;
+    // gamma(x) into layer 0's input and into every concat buffer; gamma(dir) into the view concat buffer
+    HIP_TRY(launch_embed_train(rays, ray_ld, z, ps.P, ps.S, Lx, Lv, ps.in[0], ps.in_ld[0], ps.vcat, ps.vcat_ld, a.W, s));
+    for (int i = 1; i < a.D; ++i)
+        if ((net.skip_in_mask >> i) & 1)
+            HIP_TRY(launch_embed_train(rays, ray_ld, z, ps.P, ps.S, Lx, 0, ps.in[i], ps.in_ld[i], nullptr, 0, 0, s));
+    for (int i = 0; i < a.D; ++i) {
+        const LinearDesc& d = net.linears[i];
+        GemmRows g{ps.in[i], ps.in_ld[i], wt + d.w_off, d.out, ps.h[i], ps.h_ld[i], ps.P, d.out, d.in,
+                   prm + d.b_off, 1, nullptr, 0, 0};
+        HIP_TRY(launch_gemm_rows(g, s));
+    }
+    const float* hl = ps.h[a.D - 1];
+    const int hl_ld = ps.h_ld[a.D - 1];
+    if (a.use_viewdirs) {
+        const LinearDesc &views = net.linears[a.D], &feat = net.linears[a.D + 1], &alpha = net.linears[a.D + 2],
+                         &rgb = net.linears[a.D + 3];
+        GemmRows ga{hl, hl_ld, wt + alpha.w_off, 1, ps.raw + 3, ps.C, ps.P, 1, a.W, prm + alpha.b_off, 0, nullptr, 0, 0};
+        HIP_TRY(launch_gemm_rows(ga, s));                                                  // nerf.py:86
+        GemmRows gf{hl, hl_ld, wt + feat.w_off, a.W, ps.vcat, ps.vcat_ld, ps.P, a.W, a.W, prm + feat.b_off, 0, nullptr, 0, 0};
+        HIP_TRY(launch_gemm_rows(gf, s));                                                  // nerf.py:89
+        GemmRows gv{ps.vcat, ps.vcat_ld, wt + views.w_off, views.out, ps.hv, views.out, ps.P, views.out, views.in,
+                    prm + views.b_off, 1, nullptr, 0, 0};
+        HIP_TRY(launch_gemm_rows(gv, s));                                                  // nerf.py:96-98
+        GemmRows gr{ps.hv, views.out, wt + rgb.w_off, 3, ps.raw, ps.C, ps.P, 3, rgb.in, prm + rgb.b_off, 0, nullptr, 0, 0};
+        HIP_TRY(launch_gemm_rows(gr, s));                                                  // nerf.py:101
+    } else {
+        const LinearDesc& out = net.linears[a.D + 1];
+        GemmRows go{hl, hl_ld, wt + out.w_off, out.out, ps.raw, ps.C, ps.P, out.out, a.W, prm + out.b_off, 0, nullptr, 0, 0};
+        HIP_TRY(launch_gemm_rows(go, s));                                                  // nerf.py:109
+    }
+    return NERF_OK;
+}
+
+struct TnScratch {
+    float* part;
+    int n_slices;
+    int64_t pts_per_slice;
+};
+
+// dW (+db) of one Linear: dW = dY^T X, db = dY^T 1
+int grad_linear(const PackedNet& net, const LinearDesc& d, const float* dY, int ldy, const float* X, int ldx, int64_t P,
+                const TnScratch& sc, hipStream_t s) {
+    GemmTN g{dY, ldy, X, ldx, P, d.out, d.in, 1, sc.pts_per_slice, sc.part};
+    HIP_TRY(launch_gemm_tn(g, sc.n_slices, net.train.d_grad + d.w_off, d.in, net.train.d_grad + d.b_off, s));
+    return NERF_OK;
+}
+
+int backward_pass(Pass& ps, const TnScratch& sc, hipStream_t s) {
+    const PackedNet& net = *ps.net;
+    const nerf_arch& a = net.arch;
+    const float* prm = net.d_params;
+    const float* hl = ps.h[a.D - 1];
+    const int hl_ld = ps.h_ld[a.D - 1];
+    float* dh = ps.g_a;     // gradient w.r.t. the (post-ReLU, masked to pre-activation) output of the current layer
+    float* dh_next = ps.g_b;
+    int rc;
+    if (a.use_viewdirs) {
+        const LinearDesc &views = net.linears[a.D], &feat = net.linears[a.D + 1], &alpha = net.linears[a.D + 2],
+                         &rgb = net.linears[a.D + 3];
+        // rgb_linear
+        if ((rc = grad_linear(net, rgb, ps.d_raw, ps.C, ps.hv, views.out, ps.P, sc, s))) return rc;
+        GemmRows g1{ps.d_raw, ps.C, prm + rgb.w_off, rgb.in, ps.g_hv, views.out, ps.P, views.out, 3, nullptr, 0,
+                    ps.hv, views.out, 0};
+        HIP_TRY(launch_gemm_rows(g1, s));                       // d(pre-activation of the view layer)
+        // views_linears[0]
+        if ((rc = grad_linear(net, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, ps.P, sc, s))) return rc;
+        GemmRows g2{ps.g_hv, views.out, prm + views.w_off, views.in, dh_next, a.W, ps.P, a.W, views.out, nullptr, 0,
+                    nullptr, 0, 0};
+        HIP_TRY(launch_gemm_rows(g2, s));                       // d feature (first W input columns; no ReLU on feature)
+        // feature_linear and alpha_linear both read the last trunk output
+        if ((rc = grad_linear(net, feat, dh_next, a.W, hl, hl_ld, ps.P, sc, s))) return rc;
+        if ((rc = grad_linear(net, alpha, ps.d_raw + 3, ps.C, hl, hl_ld, ps.P, sc, s))) return rc;
+        GemmRows g3{dh_next, a.W, prm + feat.w_off, a.W, dh, a.W, ps.P, a.W, a.W, nullptr, 0, nullptr, 0, 0};
+        HIP_TRY(launch_gemm_rows(g3, s));
+        GemmRows g4{ps.d_raw + 3, ps.C, prm + alpha.w_off, a.W, dh, a.W, ps.P, a.W, 1, nullptr, 0, hl, hl_ld, 1};
+        HIP_TRY(launch_gemm_rows(g4, s));                       // += dsigma * w_alpha, then ReLU mask of the trunk output
+    } else {
+        const LinearDesc& out = net.linears[a.D + 1];
+        if ((rc = grad_linear(net, out, ps.d_raw, ps.C, hl, hl_ld, ps.P, sc, s))) return rc;
+        GemmRows g1{ps.d_raw, ps.C, prm + out.w_off, a.W, dh, a.W, ps.P, a.W, out.out, nullptr, 0, hl, hl_ld, 0};
+        HIP_TRY(launch_gemm_rows(g1, s));
+        // views_linears is never evaluated without viewdirs: its gradient is zero
+        const LinearDesc& views = net.linears[a.D];
+        HIP_TRY(hipMemsetAsync(net.train.d_grad + views.w_off, 0, ((size_t)views.out * views.in + views.out) * sizeof(float), s));
+    }
+    for (int i = a.D - 1; i >= 0; --i) {
+        const LinearDesc& d = net.linears[i];
+        if ((rc = grad_linear(net, d, dh, a.W, ps.in[i], ps.in_ld[i], ps.P, sc, s))) return rc;
+        if (i == 0) break;
+        // d h_{i-1} = dh W_i[:, hidden columns] masked by ReLU'(layer i-1)
+        const int col0 = ((net.skip_in_mask >> i) & 1) ? a.input_ch : 0;
+        GemmRows g{dh, a.W, prm + d.w_off + col0, d.in, dh_next, a.W, ps.P, a.W, a.W, nullptr, 0,
+                   ps.h[i - 1], ps.h_ld[i - 1], 0};
+        HIP_TRY(launch_gemm_rows(g, s));
+        float* t = dh;
+        dh = dh_next;
+        dh_next = t;
+    }
+    return NERF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
+    if (!c || !r || !r->rays || !r->target || r->n_rays <= 0) {
+        set_error("nerf_train_step: invalid argument");
+        return NERF_E_INVALID;
+    }
+    const int64_t N = r->n_rays;
+    const int Sc = r->N_samples, Si = r->N_importance, Sf = Sc + Si;
+    if (r->ray_stride != 8 && r->ray_stride != 11) {
+        set_error("ray_stride must be 8 or 11 floats (got %d)", r->ray_stride);
+        return NERF_E_INVALID;
+    }
+    if (Sc < 1 || Si < 0 || Sf > 4096 || (Si > 0 && Sc < 3)) {
+        set_error("unsupported sample counts N_samples=%d N_importance=%d", Sc, Si);
+        return NERF_E_INVALID;
+    }
+    if (r->perturb && (!r->t_rand || (Si > 0 && !r->u_rand))) {
+        set_error("perturb > 0 requires t_rand (and u_rand with N_importance > 0): the caller owns the RNG");
+        return NERF_E_INVALID;
+    }
+    if (r->slot_coarse < 0 || r->slot_coarse >= NERF_NUM_SLOTS || !c->nets[r->slot_coarse].loaded) {
+        set_error("no weights loaded in slot %d", r->slot_coarse);
+        return NERF_E_STATE;
+    }
+    PackedNet& nc = c->nets[r->slot_coarse];
+    PackedNet* nfp = &nc;
+    if (Si > 0 && r->slot_fine >= 0) {
+        if (r->slot_fine >= NERF_NUM_SLOTS || !c->nets[r->slot_fine].loaded) {
+            set_error("no weights loaded in slot %d", r->slot_fine);
+            return NERF_E_STATE;
+        }
+        nfp = &c->nets[r->slot_fine];
+    }
+    PackedNet& nf = *nfp;
+    const bool shared = (&nf == &nc) && Si > 0;
+    if (shared) {
+        set_error("training with network_fine=None (one network for both passes) is not supported yet");
+        return NERF_E_INVALID;
+    }
+    for (PackedNet* n : {&nc, &nf}) {
+        if (n->arch.use_viewdirs && r->ray_stride < 11) {
+            set_error("the model uses viewdirs but rays carry only %d columns", r->ray_stride);
+            return NERF_E_INVALID;
+        }
+        if (n->out_ch < 4) {
+            set_error("training needs a model with >= 4 output channels");
+            return NERF_E_INVALID;
+        }
+    }
+    DeviceGuard guard(c->device);
+    hipStream_t s = (hipStream_t)r->stream;
+    int rc;
+    for (PackedNet* n : {&nc, &nf}) {
+        const bool fresh = !n->train.ready;
+        if ((rc = ensure_train_state(c, *n))) return rc;
+        if (fresh && (rc = refresh_derived(*n, s))) return rc;
+    }
+
+    // workspace: sampling buffers + both passes + split-K partials
+    const int64_t Pc = N * Sc, Pf = Si ? N * Sf : 0;
+    int n_slices = (int)((((Pf > Pc ? Pf : Pc) + 1023) / 1024));
+    if (n_slices > 256) n_slices = 256;
+    if (n_slices < 1) n_slices = 1;
+    const size_t part_floats = (size_t)n_slices * 256 * (size_t)(nc.arch.W + nc.arch.input_ch + 64);
+    const size_t small = (size_t)N * (Sc * 2 + (Si ? Si + Sf * 2 : 0) + 16) + 4096;
+    rc = ensure_workspace(c, arena_bytes({small, pass_floats(nc, Pc), Si ? pass_floats(nf, Pf) : 1, part_floats}) +
+                                 (1 << 20));
+    if (rc != NERF_OK) return rc;
+    Arena ar(c->ws);
+    float* z_c = ar.take((size_t)N * Sc);
+    float* w_c = ar.take((size_t)N * Sc);
+    float* rgb_c = ar.take((size_t)N * 3);
+    float* g_c = ar.take((size_t)N * 3);
+    float* z_s = Si ? ar.take((size_t)N * Si) : nullptr;
+    float* z_f = Si ? ar.take((size_t)N * Sf) : nullptr;
+    float* w_f = Si ? ar.take((size_t)N * Sf) : nullptr;
+    float* rgb_f = Si ? ar.take((size_t)N * 3) : nullptr;
+    float* g_f = Si ? ar.take((size_t)N * 3) : nullptr;
+    double* red = (double*)ar.take(2048);   // 2 x 512 doubles of per-block partials
+    float* loss_dev = ar.take(4);
+    TnScratch sc{ar.take(part_floats), n_slices, 0};
+
+    Pass pc;
+    pc.net = &nc;
+    pc.N = N;
+    pc.P = Pc;
+    pc.S = Sc;
+    carve_pass(ar, pc);
+    Pass pf;
+    if (Si) {
+        pf.net = &nf;
+        pf.N = N;
+        pf.P = Pf;
+        pf.S = Sf;
+        carve_pass(ar, pf);
+    }
+    auto slices_for = [&](int64_t P) {
+        int64_t pps = (P + n_slices - 1) / n_slices;
+        pps = (pps + 31) / 32 * 32;
+        return pps;
+    };
+
+    // ---- forward (render(..., retraw=True, **render_kwargs_train), nerf.ipynb:1258) ----
+    HIP_TRY(launch_stratified(r->rays, r->ray_stride, N, Sc, r->lindisp, r->perturb ? r->t_rand : nullptr, z_c, s));
+    if ((rc = forward_pass(pc, r->rays, r->ray_stride, z_c, s))) return rc;
+    HIP_TRY(launch_composite(pc.raw, pc.C, z_c, r->rays + 3, r->ray_stride, r->noise0, r->white_bkgd, N, Sc, rgb_c, nullptr,
+                             nullptr, w_c, nullptr, s));
+    if (Si) {
+        HIP_TRY(launch_sample_pdf(nullptr, w_c, Sc, 1, z_c, r->perturb ? r->u_rand : nullptr, N, Sc - 1, Si, z_s, z_f,
+                                  nullptr, s));                     // z_samples are detached (nerf.ipynb:464)
+        if ((rc = forward_pass(pf, r->rays, r->ray_stride, z_f, s))) return rc;
+        HIP_TRY(launch_composite(pf.raw, pf.C, z_f, r->rays + 3, r->ray_stride, r->noise, r->white_bkgd, N, Sf, rgb_f,
+                                 nullptr, nullptr, w_f, nullptr, s));
+    }
+    // ---- loss = img2mse(rgb, target) [+ img2mse(rgb0, target)] and its gradients (nerf.ipynb:1262-1272) ----
+    float* rgb_last = Si ? rgb_f : rgb_c;
+    HIP_TRY(launch_mse(rgb_last, r->target, N * 3, Si ? g_f : g_c, red, loss_dev, s));
+    if (Si) HIP_TRY(launch_mse(rgb_c, r->target, N * 3, g_c, red + 512, loss_dev + 1, s));
+    if (r->loss) {
+        HIP_TRY(hipMemcpyAsync(r->loss, loss_dev, sizeof(float) * (Si ? 2 : 1), hipMemcpyDeviceToDevice, s));
+    }
+    if (r->rgb_map) HIP_TRY(hipMemcpyAsync(r->rgb_map, rgb_last, (size_t)N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (r->rgb0 && Si) HIP_TRY(hipMemcpyAsync(r->rgb0, rgb_c, (size_t)N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+
+    // ---- backward ----
+    HIP_TRY(launch_composite_bwd(pc.raw, pc.C, z_c, r->rays + 3, r->ray_stride, r->noise0, r->white_bkgd, N, Sc, g_c,
+                                 pc.d_raw, s));
+    sc.pts_per_slice = slices_for(Pc);
+    if ((rc = backward_pass(pc, sc, s))) return rc;
+    nc.train.grads_valid = true;
+    if (Si) {
+        HIP_TRY(launch_composite_bwd(pf.raw, pf.C, z_f, r->rays + 3, r->ray_stride, r->noise, r->white_bkgd, N, Sf, g_f,
+                                     pf.d_raw, s));
+        sc.pts_per_slice = slices_for(Pf);
+        if ((rc = backward_pass(pf, sc, s))) return rc;
+        nf.train.grads_valid = true;
+    }
+    // ---- optimizer.step() (torch.optim.Adam, nerf.ipynb:905, :1275) ----
+    if (r->apply_update) {
+        if (r->step < 1) {
+            set_error("nerf_train_step: step must be the 1-based Adam step count");
+            return NERF_E_INVALID;
+        }
+        for (PackedNet* n : {&nc, &nf}) {
+            HIP_TRY(launch_adam(n->d_params, n->train.d_grad, n->train.d_m, n->train.d_v, (int64_t)n->n_params, r->lr,
+                                r->beta1, r->beta2, r->eps, r->step, s));
+            if ((rc = refresh_derived(*n, s))) return rc;
+            if (!Si) break;
+        }
+    }
+    return NERF_OK;
+}
+
+static int copy_flat(nerf_ctx* c, int slot, const float* d_flat, float* const* tensors, int n_tensors, const char* what) {
+    if (!c || !tensors || slot < 0 || slot >= NERF_NUM_SLOTS || !c->nets[slot].loaded) {
+        set_error("%s: invalid slot or NULL argument", what);
+        return NERF_E_INVALID;
+    }
+    PackedNet& net = c->nets[slot];
+    if (n_tensors != (int)net.linears.size() * 2) {
+        set_error("%s: expected %d tensors, got %d", what, (int)net.linears.size() * 2, n_tensors);
+        return NERF_E_INVALID;
+    }
+    if (!d_flat) {
+        set_error("%s: nothing to read (no training step has run on slot %d)", what, slot);
+        return NERF_E_STATE;
+    }
+    DeviceGuard guard(c->device);
+    HIP_TRY(hipDeviceSynchronize());
+    for (size_t k = 0; k < net.linears.size(); ++k) {
+        const LinearDesc& d = net.linears[k];
+        HIP_TRY(hipMemcpy(tensors[2 * k], d_flat + d.w_off, (size_t)d.out * d.in * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tensors[2 * k + 1], d_flat + d.b_off, (size_t)d.out * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return NERF_OK;
+}
+
+int nerf_get_weights(nerf_ctx* c, int slot, float* const* tensors, int n_tensors) {
+    return copy_flat(c, slot, (c && slot >= 0 && slot < NERF_NUM_SLOTS) ? c->nets[slot].d_params : nullptr, tensors,
+                     n_tensors, "nerf_get_weights");
+}
+
+int nerf_get_gradients(nerf_ctx* c, int slot, float* const* tensors, int n_tensors) {
+    const float* g = nullptr;
+    if (c && slot >= 0 && slot < NERF_NUM_SLOTS && c->nets[slot].train.grads_valid) g = c->nets[slot].train.d_grad;
+    return copy_flat(c, slot, g, tensors, n_tensors, "nerf_get_gradients");
+}
+
+}  // extern "C"

@@ -1,0 +1,444 @@
+// Training-step kernels: everything loss.backward() + optimizer.step() need
+// around the reference's training iteration (nerf.ipynb:1258-1282), for gfx950.
+//
+// Training keeps every layer's activations (autograd does too), so here the MLP is evaluated layer
+// by layer on explicit row-major [points, channels] buffers with two fp32-MFMA GEMM kernels:
+//   gemm_rows : C[M,N] = A[M,K] * B[K,N] (+bias, ReLU, ReLU-mask, accumulate), M = points
+//               forward  Y = X W^T + b   (B = W^T, kept transposed by the optimizer step)
+//               backward dX = dY W       (B = W as nn.Linear stores it)
+//   gemm_tn   : C[Mo,No] = sum_p A[p,Mo] * B[p,No]   (dW = dY^T X, db = dY^T 1), split over points
+//               into per-slice partials that a second kernel adds in a fixed order (deterministic)
+// Both use v_mfma_f32_32x32x2_f32 (exact fp32). At 131 kFLOP per point per 256x256 layer against 2 KB
+// of activation traffic the GEMMs stay MFMA-bound; the inference path keeps its fused kernel.
+// Plus: encode-into-concat-buffers, compositing backward (wavefront suffix scans), MSE loss + gradient,
+// Adam, weight transposes.
+#include <math.h>
+
+#include "nerf_internal.h"
+
+namespace nerf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// C[M,N] = A[M,K] * B[K,N]      (N <= 256, any K; one workgroup = 128 rows x all N columns)
+// ---------------------------------------------------------------------------------------------
+constexpr int kAsLd = 36;   // 32 + 4 pad: ds_read_b128 of 32 rows is conflict-free (bank = 36*i mod 64)
+
+__global__ __launch_bounds__(256) void gemm_rows_kernel(GemmRows g) {
+    __shared__ __attribute__((aligned(16))) float As[128 * kAsLd];
+    __shared__ __attribute__((aligned(16))) float Bs[32 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
+    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    const int n_ct = (g.N + 31) >> 5;   // column tiles in use (<= 8), uniform
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+
+    for (int k0 = 0; k0 < g.K; k0 += 32) {
+        // stage A[128 x 32] and B[32 x 256], zero filled outside the matrices; coalesced along rows
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int e = it * 256 + tid, r = e >> 5, c = e & 31;
+            const int64_t gr = row0 + r;
+            float v = 0.0f;
+            if (gr < g.M && k0 + c < g.K) v = g.A[gr * g.lda + k0 + c];
+            As[r * kAsLd + c] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 32; ++it) {
+            float v = 0.0f;
+            if (k0 + it < g.K && tid < g.N) v = g.B[(int64_t)(k0 + it) * g.ldb + tid];
+            Bs[it * 256 + tid] = v;
+        }
+        __syncthreads();
+        // lane (i = j, h) owns A[row 32*wave + i][k = 16h + t], t = 0..15 (any k order works as long as B agrees)
+        f32x4 a4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a4[q] = *(const f32x4*)&As[(32 * wave + j) * kAsLd + 16 * h + 4 * q];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c < n_ct) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    acc[c] = mfma32(a4[t >> 2][t & 3], Bs[(16 * h + t) * 256 + 32 * c + j], acc[c]);
+            }
+        }
+        __syncthreads();
+    }
+    // D[row][col]: col = lane & 31 (-> n), row = (reg & 3) + 8*(reg >> 2) + 4*h (-> point)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (c >= n_ct) continue;
+        const int n = 32 * c + j;
+        if (n >= g.N) continue;
+        const float bias = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row >= g.M) continue;
+            float v = acc[c][r];
+            float* dst = g.C + row * g.ldc + n;
+            if (g.accumulate) v += *dst;
+            if (g.bias) v += bias;
+            if (g.relu) v = fmaxf(v, 0.0f);
+            if (g.mask && !(g.mask[row * g.ldm + n] > 0.0f)) v = 0.0f;   // ReLU'(pre) = [post > 0]
+            *dst = v;
+        }
+    }
+}
+
+hipError_t launch_gemm_rows(const GemmRows& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if (g.N > 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gemm_rows_kernel, dim3((unsigned)((g.M + 127) / 128)), dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// part[slice][Mo, No(+1)] = sum over the slice's points of A[p, Mo]^T B[p, No | 1]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
+    __shared__ float As[32 * 256];
+    __shared__ float Bs[32 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
+    const int slice = blockIdx.x;
+    const int n0 = blockIdx.y * 128;
+    const int no_eff = g.No + (g.ones ? 1 : 0);
+    const int64_t p_begin = (int64_t)slice * g.pts_per_slice;
+    int64_t p_end = p_begin + g.pts_per_slice;
+    if (p_end > g.P) p_end = g.P;
+    const int m_tiles = (g.Mo + 31) >> 5;   // <= 8
+    const int mt0 = 2 * wave, mt1 = 2 * wave + 1;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
+
+    for (int64_t p0 = p_begin; p0 < p_end; p0 += 32) {
+#pragma unroll
+        for (int it = 0; it < 32; ++it) {
+            const int64_t p = p0 + it;
+            float v = 0.0f;
+            if (p < p_end && tid < g.Mo) v = g.A[p * g.lda + tid];
+            As[it * 256 + tid] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int e = it * 256 + tid, pr = e >> 7, c = e & 127;
+            const int64_t p = p0 + pr;
+            const int n = n0 + c;
+            float v = 0.0f;
+            if (p < p_end) {
+                if (n < g.No) v = g.B[p * g.ldb + n];
+                else if (n == g.No && g.ones) v = 1.0f;
+            }
+            Bs[pr * 128 + c] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int pr = 16 * h + t;   // contraction index (the point) of this lane half for k-step t
+            const float a0 = As[pr * 256 + 32 * mt0 + j], a1 = As[pr * 256 + 32 * mt1 + j];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float b = Bs[pr * 128 + 32 * c + j];
+                acc[0][c] = mfma32(a0, b, acc[0][c]);
+                acc[1][c] = mfma32(a1, b, acc[1][c]);
+            }
+        }
+        __syncthreads();
+    }
+    float* part = g.part + (int64_t)slice * g.Mo * no_eff;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int mt = a ? mt1 : mt0;
+        if (mt >= m_tiles) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int n = n0 + 32 * c + j;
+            if (n >= no_eff) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < g.Mo) part[(int64_t)m * no_eff + n] = acc[a][c][r];
+            }
+        }
+    }
+}
+
+// dW[m][n] = sum_s part[s][m][n] in slice order; column No (if present) goes to db[m]
+__global__ void reduce_slices_kernel(const float* __restrict__ part, int n_slices, int Mo, int No, int ones,
+                                     float* __restrict__ dW, int ldw, float* __restrict__ db) {
+    const int no_eff = No + (ones ? 1 : 0);
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)Mo * no_eff) return;
+    const int m = (int)(idx / no_eff), n = (int)(idx % no_eff);
+    float s = 0.0f;
+    for (int k = 0; k < n_slices; ++k) s += part[(int64_t)k * Mo * no_eff + idx];
+    if (n < No) dW[(int64_t)m * ldw + n] = s;
+    else if (db) db[m] = s;
+}
+
+hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, float* db, hipStream_t s) {
+    if (g.Mo <= 0 || g.No <= 0) return hipSuccess;
+    if (g.Mo > 256) return hipErrorInvalidValue;
+    const int no_eff = g.No + (g.ones ? 1 : 0);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)n_slices, (unsigned)((no_eff + 127) / 128)), dim3(256), 0, s, g);
+    const int64_t total = (int64_t)g.Mo * no_eff;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g.part, n_slices,
+                       g.Mo, g.No, g.ones, dW, ldw, db);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// inputs: pts = o + d z, gamma(pts) -> xcat[:, 0:in_ch] (ld ldx), gamma(viewdir) -> vcat[:, voff: voff+in_ch_views]
+// ---------------------------------------------------------------------------------------------
+__global__ void embed_train_kernel(const float* __restrict__ rays, int ray_ld, const float* __restrict__ z, int64_t P,
+                                   int S, int Lx, int Lv, float* __restrict__ xcat, int ldx, float* __restrict__ vcat,
+                                   int ldv, int voff) {
+    const int64_t pt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= P) return;
+    const float* r = rays + (pt / S) * ray_ld;
+    const float zz = z[pt];
+    float* xo = xcat + pt * ldx;
+    for (int c = 0; c < 3; ++c) {
+        const float p = __fadd_rn(r[c], __fmul_rn(r[3 + c], zz));   // nerf.ipynb:447
+        xo[c] = p;
+        for (int k = 0; k < Lx; ++k) {
+            float sn, cs;
+            sincosf(p * (float)(1 << k), &sn, &cs);
+            xo[3 + 6 * k + c] = sn;
+            xo[3 + 6 * k + 3 + c] = cs;
+        }
+    }
+    if (vcat) {
+        float* vo = vcat + pt * ldv + voff;
+        for (int c = 0; c < 3; ++c) {
+            const float d = r[ray_ld - 3 + c];
+            vo[c] = d;
+            for (int k = 0; k < Lv; ++k) {
+                float sn, cs;
+                sincosf(d * (float)(1 << k), &sn, &cs);
+                vo[3 + 6 * k + c] = sn;
+                vo[3 + 6 * k + 3 + c] = cs;
+            }
+        }
+    }
+}
+
+hipError_t launch_embed_train(const float* rays, int ray_ld, const float* z, int64_t P, int S, int Lx, int Lv,
+                              float* xcat, int ldx, float* vcat, int ldv, int voff, hipStream_t s) {
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(embed_train_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, rays, ray_ld, z, P, S,
+                       Lx, Lv, xcat, ldx, vcat, ldv, voff);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// loss = mean((rgb - target)^2) (img2mse, nerf_helpers.py:8); grad = 2 (rgb - target) / numel
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wsumf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                          int64_t n, float* __restrict__ grad, double* __restrict__ part) {
+    double s = 0.0;
+    const float scale = 2.0f / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = __fsub_rn(x[i], t[i]);
+        s += (double)__fmul_rn(d, d);
+        if (grad) grad[i] = __fmul_rn(scale, d);
+    }
+    __shared__ double red[4];
+    s = wsum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void mse_final_kernel(const double* __restrict__ part, int nb, double n, float* __restrict__ loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nb; ++i) s += part[i];
+        *loss = (float)(s / n);
+    }
+}
+
+hipError_t launch_mse(const float* x, const float* t, int64_t n, float* grad, double* part, float* loss, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    int nb = (int)((n + 255) / 256);
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(nb), dim3(256), 0, s, x, t, n, grad, part);
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, s, part, nb, (double)n, loss);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of raw2outputs (nerf.ipynb:254-349) w.r.t. raw for a loss on rgb_map only:
+//   rgb_map = sum_i w_i c_i (+ 1 - sum_i w_i with white_bkgd), w_i = alpha_i T_i, T_i = prod_{j<i}(1-alpha_j+1e-10)
+//   dL/dc_i = g w_i ;  dL/dalpha_k = g.(T_k c_k - S_k/(1-alpha_k+1e-10)) - bg (T_k - A_k/(1-alpha_k+1e-10))
+//   with suffix sums S_k = sum_{i>k} w_i c_i, A_k = sum_{i>k} w_i and bg = sum(g) for white_bkgd.
+// One wavefront per ray; suffix sums are wavefront scans run from the far end.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restrict__ raw, int C,
+                                                           const float* __restrict__ z_vals,
+                                                           const float* __restrict__ rays_d, int d_ld,
+                                                           const float* __restrict__ noise, int white_bkgd, int S,
+                                                           const float* __restrict__ g_rgb, float* __restrict__ d_raw) {
+    extern __shared__ float Tsh[];   // exclusive transmittance of every sample of this ray
+    const int64_t ray = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float* d = rays_d + ray * d_ld;
+    const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+    const float* z = z_vals + ray * S;
+    const float* rw = raw + ray * (int64_t)S * C;
+    float* dr = d_raw + ray * (int64_t)S * C;
+    const float g0 = g_rgb[ray * 3 + 0], g1 = g_rgb[ray * 3 + 1], g2 = g_rgb[ray * 3 + 2];
+    const float gbg = white_bkgd ? (g0 + g1 + g2) : 0.0f;
+
+    auto alpha_at = [&](int i, float& dist, float& sig) {
+        dist = __fmul_rn(i < S - 1 ? __fsub_rn(z[i + 1], z[i]) : 1e10f, norm);
+        sig = rw[(int64_t)i * C + 3];
+        if (noise) sig = __fadd_rn(sig, noise[ray * S + i]);
+        return __fsub_rn(1.0f, expf(__fmul_rn(-fmaxf(sig, 0.0f), dist)));
+    };
+    // forward pass: T_i exactly as the forward kernel computes it (fp64 scan, each prefix rounded to fp32)
+    double carry_t = 1.0;
+    for (int base = 0; base < S; base += 64) {
+        const int i = base + lane;
+        float dist, sig;
+        const float alpha = i < S ? alpha_at(i, dist, sig) : 0.0f;
+        double v = i < S ? (double)__fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f) : 1.0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double nb = __shfl_up(v, o);
+            if (lane >= o) v *= nb;
+        }
+        double excl = __shfl_up(v, 1);
+        if (lane == 0) excl = 1.0;
+        if (i < S) Tsh[i] = (float)(carry_t * excl);
+        carry_t *= __shfl(v, 63);
+    }
+    __syncthreads();
+    // backward pass from the far end; carry = sum over samples beyond this round of w_i (g.c_i - gbg)
+    float carry = 0.0f;
+    for (int rd = (S + 63) / 64 - 1; rd >= 0; --rd) {
+        const int i = rd * 64 + lane;
+        const bool on = i < S;
+        float wi = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, alpha = 0.0f, dist = 0.0f, sig = 0.0f, T = 0.0f;
+        if (on) {
+            alpha = alpha_at(i, dist, sig);
+            T = Tsh[i];
+            wi = __fmul_rn(alpha, T);
+            c0 = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw[(int64_t)i * C + 0])));
+            c1 = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw[(int64_t)i * C + 1])));
+            c2 = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw[(int64_t)i * C + 2])));
+        }
+        const float gc = g0 * c0 + g1 * c1 + g2 * c2;
+        const float q = on ? wi * (gc - gbg) : 0.0f;
+        float incl = q;   // inclusive suffix sum over lanes (from lane 63 down)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float nb = __shfl_down(incl, o);
+            if (lane + o < 64) incl += nb;
+        }
+        const float suffix_excl = incl - q + carry;   // sum_{i' > i} w_i' (g.c_i' - gbg)
+        carry += __shfl(incl, 0);
+        if (on) {
+            const float om = __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f);
+            const float dalpha_dsig = sig > 0.0f ? dist * (1.0f - alpha) : 0.0f;   // d/dsigma of 1 - exp(-relu(sigma) dist)
+            dr[(int64_t)i * C + 0] = g0 * wi * c0 * (1.0f - c0);
+            dr[(int64_t)i * C + 1] = g1 * wi * c1 * (1.0f - c1);
+            dr[(int64_t)i * C + 2] = g2 * wi * c2 * (1.0f - c2);
+            dr[(int64_t)i * C + 3] = dalpha_dsig * (T * (gc - gbg) - suffix_excl / om);
+            for (int c = 4; c < C; ++c) dr[(int64_t)i * C + c] = 0.0f;
+        }
+    }
+}
+
+hipError_t launch_composite_bwd(const float* raw, int C, const float* z, const float* rays_d, int d_ld,
+                                const float* noise, int white_bkgd, int64_t N, int S, const float* g_rgb,
+                                float* d_raw, hipStream_t s) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)N), dim3(64), (size_t)S * sizeof(float), s, raw, C, z,
+                       rays_d, d_ld, noise, white_bkgd, S, g_rgb, d_raw);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam defaults except lr/betas given at nerf.ipynb:905), transposes
+// ---------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2_sqrt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = m[i] + (1.0f - b1) * (gi - m[i]);              // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                       int step, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps,
+                       bc1, bc2_sqrt);
+    return hipGetLastError();
+}
+
+__global__ void transpose_kernel(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    dst[(int64_t)c * rows + r] = src[i];
+}
+
+hipError_t launch_transpose(const float* src, int rows, int cols, float* dst, hipStream_t s) {
+    const int64_t n = (int64_t)rows * cols;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, rows, cols, dst);
+    return hipGetLastError();
+}
+
+// stream[i] = table[i] >= 0 ? params[table[i]] : 0   (re-pack of the fused inference stream after an update)
+__global__ void gather_kernel(const float* __restrict__ params, const int* __restrict__ table, int64_t n,
+                              float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = table[i];
+    out[i] = t >= 0 ? params[t] : 0.0f;
+}
+
+hipError_t launch_gather(const float* params, const int* table, int64_t n, float* out, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, params, table, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace nerf

@@ -16,13 +16,13 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Camera, NerfArch, RenderArgs, check
+from ._lib import Camera, NerfArch, RenderArgs, TrainArgs, check
 
 __all__ = [
     "NeRF", "get_embedder", "batchify", "run_network", "raw2outputs", "sample_pdf", "render_rays",
     "batchify_rays", "render", "get_rays", "get_rays_np", "ndc_rays", "make_network_query_fn",
     "get_context", "img2mse", "mse2psnr", "to8b", "generate_rays", "render_path", "calculate_ssim",
-    "calculate_lpips", "calculate_metrics", "create_nerf", "load_checkpoint",
+    "calculate_lpips", "calculate_metrics", "create_nerf", "load_checkpoint", "Adam", "train_on_batch",
 ]
 
 
@@ -181,10 +181,23 @@ class NeRF:
         self._sd = dict(zip(keys, arrays))
         return self
 
+    def _read_flat(self, fn):
+        keys = self.state_dict_keys()
+        arrays = [np.empty(self._expected_shape(k), dtype=np.float32) for k in keys]
+        ptrs = (C.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
+        check(fn(self.ctx.handle, self.slot, ptrs, len(arrays)))
+        return dict(zip(keys, arrays))
+
     def state_dict(self):
+        """The current weights (read back from the device, so training updates are visible)."""
         if self._sd is None:
             raise RuntimeError("no weights loaded")
+        self._sd = self._read_flat(self.ctx.lib.nerf_get_weights)
         return {k: torch.from_numpy(v.copy()) for k, v in self._sd.items()}
+
+    def grad_dict(self):
+        """Gradients of the last training step, keyed like the state dict (``param.grad``)."""
+        return {k: torch.from_numpy(v) for k, v in self._read_flat(self.ctx.lib.nerf_get_gradients).items()}
 
     def parameters(self):
         """Yields device placeholders so ``next(fn.parameters()).device`` works (nerf.ipynb:598, :848)."""
@@ -792,6 +805,104 @@ def create_nerf(args, device=None):
     render_kwargs_test['perturb'] = False
     render_kwargs_test['raw_noise_std'] = 0.
     return render_kwargs_train, render_kwargs_test, start, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# training iteration (nerf.ipynb:905, 1258-1282)
+# ----------------------------------------------------------------------------------------------
+
+class Adam:
+    """Stand-in for ``torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))``
+    (nerf.ipynb:905) over this package's models: the moments live next to the master weights on the
+    device and the update runs inside :func:`train_on_batch`. ``param_groups[0]['lr']`` is writable so
+    the reference's decay loop (nerf.ipynb:1278-1282) works unchanged."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.models = [m for m in params if isinstance(m, NeRF)]
+        if not self.models:
+            raise ValueError("Adam expects the NeRF models themselves (their parameters live on the device)")
+        self.param_groups = [{'lr': float(lr), 'betas': tuple(betas), 'eps': float(eps)}]
+        self.steps = 0
+
+    def zero_grad(self):
+        pass                      # gradients are overwritten by every backward pass
+
+    def state_dict(self):
+        return {'steps': self.steps, 'param_groups': [dict(g) for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.steps = int(sd.get('steps', 0))
+
+
+def train_on_batch(H, W, K, batch_rays, target_s, optimizer, chunk=1024 * 32, ndc=True, near=0., far=1.,
+                   use_viewdirs=False, network_fn=None, network_query_fn=None, N_samples=64, N_importance=0,
+                   network_fine=None, perturb=0., raw_noise_std=0., white_bkgd=False, lindisp=False, pytest=False,
+                   apply_update=True, **unused):
+    """One iteration of the reference's training loop body (nerf.ipynb:1258-1282) on the GPU:
+    ``render(H, W, K, rays=batch_rays, retraw=True, **render_kwargs_train)``, ``img_loss =
+    img2mse(rgb, target_s)`` (``+ img2mse(rgb0, target_s)``), ``loss.backward()``, ``optimizer.step()``.
+    Pass the same ``render_kwargs_train`` (plus ``near``/``far``) as keyword arguments. Returns
+    ``{'loss','img_loss','psnr'[, 'img_loss0','psnr0'], 'rgb'[, 'rgb0']}`` (tensors on the device)."""
+    if not isinstance(network_fn, NeRF) or (N_importance > 0 and not isinstance(network_fine, NeRF)):
+        raise TypeError("train_on_batch needs this package's NeRF models (a distinct network_fine when "
+                        "N_importance > 0)")
+    ctx = network_fn.ctx
+    packed, _ = pack_rays(H, W, K, batch_rays, None, ndc, near, far, use_viewdirs, None, device=ctx.device)
+    packed = packed.contiguous()
+    target = _dev(target_s, ctx).reshape(-1, 3)
+    N, stride = packed.shape
+    if target.shape[0] != N:
+        raise RuntimeError(f"target_s has {target.shape[0]} rows for {N} rays")
+    Sc, Si = int(N_samples), int(N_importance)
+    o = dict(device=ctx.device, dtype=torch.float32)
+    a = TrainArgs()
+    a.rays, a.target, a.n_rays, a.ray_stride = packed.data_ptr(), target.data_ptr(), N, stride
+    a.N_samples, a.N_importance = Sc, Si
+    a.slot_coarse, a.slot_fine = network_fn.slot, (network_fine.slot if Si > 0 else -1)
+    a.lindisp, a.white_bkgd = int(bool(lindisp)), int(bool(white_bkgd))
+    keep = [packed, target]
+    perturb = float(perturb)
+
+    def draw(shape, normal=False):            # the reference's RNG order, incl. its pytest re-seeding
+        if pytest:
+            np.random.seed(0)
+            return _dev(np.random.rand(*shape), ctx)
+        return torch.randn(shape, **o) if normal else torch.rand(shape, **o)
+
+    if perturb > 0.:
+        a.perturb = 1
+        t_rand = draw((N, Sc))
+        keep.append(t_rand)
+        a.t_rand = t_rand.data_ptr()
+    n0 = _noise((N, Sc), raw_noise_std, pytest, ctx)
+    if n0 is not None:
+        keep.append(n0)
+        a.noise0 = n0.data_ptr()
+    if Si > 0:
+        if perturb > 0.:
+            u = draw((N, Si))
+            keep.append(u)
+            a.u_rand = u.data_ptr()
+        n1 = _noise((N, Sc + Si), raw_noise_std, pytest, ctx)
+        if n1 is not None:
+            keep.append(n1)
+            a.noise = n1.data_ptr()
+    g = optimizer.param_groups[0]
+    a.lr, (a.beta1, a.beta2), a.eps = g['lr'], g['betas'], g['eps']
+    a.apply_update = int(bool(apply_update))
+    if apply_update:
+        optimizer.steps += 1
+    a.step = max(optimizer.steps, 1)
+    loss = torch.zeros(2, **o)
+    rgb = torch.empty((N, 3), **o)
+    rgb0 = torch.empty((N, 3), **o) if Si > 0 else None
+    a.loss, a.rgb_map, a.rgb0 = loss.data_ptr(), rgb.data_ptr(), (rgb0.data_ptr() if Si > 0 else None)
+    a.stream = ctx.stream().value
+    check(ctx.lib.nerf_train_step(ctx.handle, C.byref(a)))
+    out = {'img_loss': loss[0], 'psnr': mse2psnr(loss[0]), 'rgb': rgb, 'loss': loss[0]}
+    if Si > 0:
+        out.update(img_loss0=loss[1], psnr0=mse2psnr(loss[1]), rgb0=rgb0, loss=loss[0] + loss[1])
+    return out
 
 
 # ----------------------------------------------------------------------------------------------

@@ -385,6 +385,48 @@ def gold_metrics():
     save("metrics", img1=a, img2=b, mse=m["mse"], psnr=m["psnr"], ssim=m["ssim"], ssim_same=ssim_same)
 
 
+def gold_train():
+    """Two iterations of the reference's training loop body (nerf.ipynb:1258-1282) on 32 rays with its
+    pytest RNG: loss values, gradients after the first backward and weights after two Adam steps.
+    Gradients / weights are stored as per-tensor L2 norms plus every 61st element (fixtures stay small)."""
+    g = np.load(os.path.join(HERE, "render_rays_lego.npz"))
+    rays = torch.from_numpy(g["rays"][:32])
+    rs = np.random.RandomState(106)
+    target = torch.from_numpy(rs.uniform(0, 1, size=(32, 3)).astype(np.float32))
+    net_c, net_f = ref_pair(0)
+    net_c.train(); net_f.train()
+    e_fn, _ = ref_embedder.get_embedder(10, 0)
+    ed_fn, _ = ref_embedder.get_embedder(4, 0)
+    params = list(net_c.parameters()) + list(net_f.parameters())
+    opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999))
+    kw = dict(N_samples=64, N_importance=128, retraw=True, white_bkgd=True, perturb=1.0, raw_noise_std=1.0,
+              pytest=True)
+    out = {}
+    names_c = [k for k, _ in net_c.named_parameters()]
+    for it in range(2):
+        ret = NS["render_rays"](rays, net_c, query_fn(e_fn, ed_fn), network_fine=net_f, **kw)
+        opt.zero_grad()
+        img_loss = ref_helpers.img2mse(ret["rgb_map"], target)
+        img_loss0 = ref_helpers.img2mse(ret["rgb0"], target)
+        loss = img_loss + img_loss0
+        loss.backward()
+        out[f"img_loss_{it}"] = n(img_loss)
+        out[f"img_loss0_{it}"] = n(img_loss0)
+        if it == 0:
+            out["rgb_0"] = n(ret["rgb_map"])
+            for tag, net in (("c", net_c), ("f", net_f)):
+                for k, p in net.named_parameters():
+                    gr = n(p.grad).reshape(-1) if p.grad is not None else np.zeros(p.numel(), np.float32)
+                    out[f"gnorm_{tag}.{k}"] = np.linalg.norm(gr.astype(np.float64))
+                    out[f"gsub_{tag}.{k}"] = gr[::61].copy()
+        opt.step()
+    for tag, net in (("c", net_c), ("f", net_f)):
+        for k, p in net.named_parameters():
+            w = n(p).reshape(-1)
+            out[f"wsub_{tag}.{k}"] = w[::61].copy()
+    save("train_step", rays=n(rays), target=n(target), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -398,3 +440,4 @@ if __name__ == "__main__":
     gold_render()
     gold_ray_packing()
     gold_metrics()
+    gold_train()
