@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Secondary benchmark: training iterations per second.
+
+The reference's stored run trains at 5.6-7.4 it/s with N_rand = 1024 rays per iteration
+(ship, 96+192 samples, unknown CUDA GPU). This times the same loop body
+(nerf.ipynb:1258-1282: render with the training kwargs, two MSE losses, backward, Adam, lr decay)
+on one MI355X with synthetic rays/targets and seeded weights.
+
+    python bench_train.py [--iters 50] [--n-rand 1024] [--samples 64 --importance 128]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--iters", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--n-rand", type=int, default=1024)
+    p.add_argument("--samples", type=int, default=64)
+    p.add_argument("--importance", type=int, default=128)
+    a = p.parse_args()
+    import nerf_projects_amd as N
+    from nerf_projects_amd import synthetic
+    torch.cuda.set_device(0)
+    sd_c, sd_f = synthetic.synthetic_pair(0)
+    mk = dict(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+    net_c, net_f = N.NeRF(**mk).load_state_dict(sd_c), N.NeRF(**mk).load_state_dict(sd_f)
+    opt = N.Adam([net_c, net_f], lr=5e-4, betas=(0.9, 0.999))
+    K, c2w, near, far = synthetic.lego_camera(800, 800)
+    packed = N.generate_rays(800, 800, K, c2w, ndc=False, near=near, far=far, use_viewdirs=True)
+    kw = dict(network_fn=net_c, network_fine=net_f, N_samples=a.samples, N_importance=a.importance, white_bkgd=True,
+              perturb=1.0, raw_noise_std=1.0, ndc=False, use_viewdirs=True, near=near, far=far)
+    rs = np.random.RandomState(0)
+    lrate, lrate_decay = 5e-4, 500
+
+    def one(i):
+        idx = torch.from_numpy(rs.choice(packed.shape[0], a.n_rand, replace=False)).cuda()
+        r = packed[idx]
+        target = torch.rand((a.n_rand, 3), device="cuda")
+        out = N.train_on_batch(800, 800, K, (r[:, 0:3], r[:, 3:6]), target, opt, **kw)
+        opt.param_groups[0]['lr'] = lrate * (0.1 ** (i / (lrate_decay * 1000)))     # nerf.ipynb:1278-1282
+        return out
+
+    for i in range(a.warmup):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.iters):
+        out = one(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    evals = a.n_rand * (a.samples + (a.samples + a.importance if a.importance else 0))
+    flops = evals * 1186816 * 3          # forward + dX + dW
+    print(json.dumps({"metric": "train_iterations_per_sec", "value": a.iters / dt, "unit": "it/s",
+                      "ms_per_iter": dt / a.iters * 1e3, "n_rand": a.n_rand, "N_samples": a.samples,
+                      "N_importance": a.importance, "mlp_evals_per_iter": evals,
+                      "approx_tflops": flops * a.iters / dt / 1e12, "final_loss": float(out["loss"]),
+                      "reference_stored_run_it_per_s": "5.6-7.4 (ship 96+192, unknown CUDA GPU; BASELINE.md)"}))
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,8 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kAsLd = 36;   // 32 + 4 pad: ds_read_b128 of 32 rows is conflict-free (bank = 36*i mod 64)
 
+// The next k-tile's global loads are issued into registers before the current tile's MFMAs and
+// written to LDS after them (global latency hides under 128 MFMAs per wave).
 __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmRows g) {
     __shared__ __attribute__((aligned(16))) float As[128 * kAsLd];
     __shared__ __attribute__((aligned(16))) float Bs[32 * 256];
@@ -43,23 +45,34 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmRows g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
 
-    for (int k0 = 0; k0 < g.K; k0 += 32) {
-        // stage A[128 x 32] and B[32 x 256], zero filled outside the matrices; coalesced along rows
+    float ra[16], rb[32];
+    auto load_tile = [&](int k0) {   // A[128 x 32] and B[32 x 256], zero filled outside; coalesced along rows
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int e = it * 256 + tid, r = e >> 5, c = e & 31;
             const int64_t gr = row0 + r;
-            float v = 0.0f;
-            if (gr < g.M && k0 + c < g.K) v = g.A[gr * g.lda + k0 + c];
-            As[r * kAsLd + c] = v;
+            ra[it] = (gr < g.M && k0 + c < g.K) ? g.A[gr * g.lda + k0 + c] : 0.0f;
         }
 #pragma unroll
-        for (int it = 0; it < 32; ++it) {
-            float v = 0.0f;
-            if (k0 + it < g.K && tid < g.N) v = g.B[(int64_t)(k0 + it) * g.ldb + tid];
-            Bs[it * 256 + tid] = v;
+        for (int it = 0; it < 32; ++it)
+            rb[it] = (k0 + it < g.K && tid < g.N) ? g.B[(int64_t)(k0 + it) * g.ldb + tid] : 0.0f;
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int e = it * 256 + tid;
+            As[(e >> 5) * kAsLd + (e & 31)] = ra[it];
         }
-        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 32; ++it) Bs[it * 256 + tid] = rb[it];
+    };
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int k0 = 0; k0 < g.K; k0 += 32) {
+        const bool more = k0 + 32 < g.K;
+        if (more) load_tile(k0 + 32);
         // lane (i = j, h) owns A[row 32*wave + i][k = 16h + t], t = 0..15 (any k order works as long as B agrees)
         f32x4 a4[4];
 #pragma unroll
@@ -73,6 +86,10 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmRows g) {
             }
         }
         __syncthreads();
+        if (more) {
+            store_tile();
+            __syncthreads();
+        }
     }
     // D[row][col]: col = lane & 31 (-> n), row = (reg & 3) + 8*(reg >> 2) + 4*h (-> point)
 #pragma unroll
@@ -127,13 +144,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
 
-    for (int64_t p0 = p_begin; p0 < p_end; p0 += 32) {
+    float ra[32], rb[16];
+    auto load_tile = [&](int64_t p0) {
 #pragma unroll
         for (int it = 0; it < 32; ++it) {
             const int64_t p = p0 + it;
-            float v = 0.0f;
-            if (p < p_end && tid < g.Mo) v = g.A[p * g.lda + tid];
-            As[it * 256 + tid] = v;
+            ra[it] = (p < p_end && tid < g.Mo) ? g.A[p * g.lda + tid] : 0.0f;
         }
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
@@ -145,9 +161,27 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
                 if (n < g.No) v = g.B[p * g.ldb + n];
                 else if (n == g.No && g.ones) v = 1.0f;
             }
-            Bs[pr * 128 + c] = v;
+            rb[it] = v;
         }
-        __syncthreads();
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < 32; ++it) As[it * 256 + tid] = ra[it];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int e = it * 256 + tid;
+            Bs[(e >> 7) * 128 + (e & 127)] = rb[it];
+        }
+    };
+
+    if (p_begin < p_end) {
+        load_tile(p_begin);
+        store_tile();
+    }
+    __syncthreads();
+    for (int64_t p0 = p_begin; p0 < p_end; p0 += 32) {
+        const bool more = p0 + 32 < p_end;
+        if (more) load_tile(p0 + 32);
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int pr = 16 * h + t;   // contraction index (the point) of this lane half for k-step t
@@ -160,6 +194,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
             }
         }
         __syncthreads();
+        if (more) {
+            store_tile();
+            __syncthreads();
+        }
     }
     float* part = g.part + (int64_t)slice * g.Mo * no_eff;
 #pragma unroll
