@@ -199,6 +199,20 @@ class NeRF:
         """Gradients of the last training step, keyed like the state dict (``param.grad``)."""
         return {k: torch.from_numpy(v) for k, v in self._read_flat(self.ctx.lib.nerf_get_gradients).items()}
 
+    def load_weights_from_keras(self, weights):
+        """nerf/nerf.py:113-146: weights of the original TensorFlow NeRF as a flat list
+        ``[kernel, bias] * D, feature, views, rgb, alpha`` with Keras ``[in, out]`` kernels."""
+        assert self.use_viewdirs, "Not implemented if use_viewdirs=False"
+        sd = {}
+        for i in range(self.D):
+            sd[f"pts_linears.{i}.weight"] = np.transpose(np.asarray(weights[2 * i]))
+            sd[f"pts_linears.{i}.bias"] = np.transpose(np.asarray(weights[2 * i + 1]))
+        for name, idx in (("feature_linear", 2 * self.D), ("views_linears.0", 2 * self.D + 2),
+                          ("rgb_linear", 2 * self.D + 4), ("alpha_linear", 2 * self.D + 6)):
+            sd[name + ".weight"] = np.transpose(np.asarray(weights[idx]))
+            sd[name + ".bias"] = np.transpose(np.asarray(weights[idx + 1]))
+        return self.load_state_dict(sd)
+
     def parameters(self):
         """Yields device placeholders so ``next(fn.parameters()).device`` works (nerf.ipynb:598, :848)."""
         yield torch.empty(0, device=self.ctx.device)

@@ -541,3 +541,88 @@ def test_two_adam_steps_match_reference(N, weights_pair):
                          network_fine=make_net(N, weights_pair[1]), white_bkgd=True)
     assert np.abs(cpu(ret["rgb0"]) - cpu(ret0["rgb0"])).max() > 1e-4
     assert torch.isfinite(ret["rgb_map"]).all()
+
+
+# ---- further configurations of the reference's YAMLs and edge shapes --------------------------------
+
+def test_ship_config_96_192(N, O, nets):
+    """nerf/yaml/ship_blender200k_fullres_higher_samples: N_samples=96, N_importance=192 (288 fine samples:
+    five 64-sample compositing rounds, a 512-entry merge sort), chunk 20480."""
+    net_c, net_f, q = nets
+    g = load_golden("render_rays_lego")
+    rays = g["rays"][:48]
+    ret = N.render_rays(gpu(rays), net_c, q, N_samples=96, N_importance=192, network_fine=net_f, white_bkgd=True,
+                        retraw=True)
+    assert ret["raw"].shape == (48, 288, 4)
+    oq = O.make_query_fn(O.get_embedder(10)[0], O.get_embedder(4)[0])
+    want = O.render_rays(rays, O.NeRF(8, 256, 63, 27, 4, (4,), True, net_c._sd), oq, N_samples=96, N_importance=192,
+                         network_fine=O.NeRF(8, 256, 63, 27, 4, (4,), True, net_f._sd), white_bkgd=True)
+    assert np.abs(cpu(ret["rgb0"]) - want["rgb0"]).max() <= 1e-5
+    check_end_to_end(cpu(ret["rgb_map"]), want["rgb_map"])
+
+
+def test_small_and_odd_shapes(N, O, nets):
+    net_c, net_f, q = nets
+    g = load_golden("render_rays_lego")
+    oq = O.make_query_fn(O.get_embedder(10)[0], O.get_embedder(4)[0])
+    onc = O.NeRF(8, 256, 63, 27, 4, (4,), True, net_c._sd)
+    onf = O.NeRF(8, 256, 63, 27, 4, (4,), True, net_f._sd)
+    for n_rays, Sc, Si in ((1, 3, 1), (5, 7, 9), (33, 65, 63), (3, 1, 0)):
+        rays = g["rays"][:n_rays]
+        kw = dict(N_samples=Sc, N_importance=Si, white_bkgd=True)
+        ret = N.render_rays(gpu(rays), net_c, q, network_fine=net_f if Si else None, **kw)
+        want = O.render_rays(rays, onc, oq, network_fine=onf if Si else None, **kw)
+        key = "rgb0" if Si else "rgb_map"
+        assert np.abs(cpu(ret[key]) - want[key]).max() <= 1e-5, (n_rays, Sc, Si)
+        assert ret["rgb_map"].shape == (n_rays, 3)
+        if Si:      # a handful of rays: plain bound instead of the distributional criterion
+            assert np.abs(cpu(ret["rgb_map"]) - want["rgb_map"]).max() <= 2e-4, (n_rays, Sc, Si)
+
+
+def test_architecture_variants_end_to_end(N, O):
+    """Depth / skip variants through the fused ray pipeline (the MLP-only variants are in test_mlp_forward)."""
+    g = load_golden("render_rays_lego")
+    rays = g["rays"][:40]
+    for seed, arch in ((21, dict(D=2, skips=())), (22, dict(D=6, skips=(1, 3))), (23, dict(D=3, skips=(0,)))):
+        sd = synthetic.synthetic_state_dict(seed, **arch)
+        net = make_net(N, sd, D=arch["D"], skips=list(arch["skips"]))
+        q = N.make_network_query_fn(N.get_embedder(10, 0)[0], N.get_embedder(4, 0)[0])
+        ret = N.render_rays(gpu(rays), net, q, N_samples=32, white_bkgd=True, retraw=True)
+        onet = O.NeRF(arch["D"], 256, 63, 27, 4, arch["skips"], True, sd)
+        want = O.render_rays(rays, onet, O.make_query_fn(O.get_embedder(10)[0], O.get_embedder(4)[0]), N_samples=32,
+                             white_bkgd=True, retraw=True)
+        scale = max(1.0, np.abs(want["raw"]).max())
+        assert np.abs(cpu(ret["raw"]) - want["raw"]).max() <= 5e-6 * scale, arch
+        assert np.abs(cpu(ret["rgb_map"]) - want["rgb_map"]).max() <= 1e-5, arch
+
+
+def test_low_multires_and_identity_embedding(N, O):
+    """multires < 10 / multires_views < 4 and i_embed = -1 (3 raw channels) use zero-weight padding of the
+    encoded tiles; results must still match the oracle."""
+    g = load_golden("render_rays_lego")
+    rays = g["rays"][:40]
+    for seed, L, Lv, i_embed in ((31, 6, 2, 0), (32, 10, 4, -1)):
+        in_ch = 3 if i_embed == -1 else 3 + 6 * L
+        in_v = 3 if i_embed == -1 else 3 + 6 * Lv
+        sd = synthetic.synthetic_state_dict(seed, input_ch=in_ch, input_ch_views=in_v)
+        net = make_net(N, sd, input_ch=in_ch, input_ch_views=in_v)
+        q = N.make_network_query_fn(N.get_embedder(L, i_embed)[0], N.get_embedder(Lv, i_embed)[0])
+        ret = N.render_rays(gpu(rays), net, q, N_samples=32, white_bkgd=True, retraw=True)
+        onet = O.NeRF(8, 256, in_ch, in_v, 4, (4,), True, sd)
+        oq = O.make_query_fn(O.get_embedder(L, i_embed)[0], O.get_embedder(Lv, i_embed)[0])
+        want = O.render_rays(rays, onet, oq, N_samples=32, white_bkgd=True, retraw=True)
+        scale = max(1.0, np.abs(want["raw"]).max())
+        assert np.abs(cpu(ret["raw"]) - want["raw"]).max() <= 5e-6 * scale, (L, Lv, i_embed)
+
+
+def test_load_weights_from_keras(N):
+    sd = synthetic.synthetic_state_dict(7)
+    keras = []
+    for i in range(8):
+        keras += [sd[f"pts_linears.{i}.weight"].T.copy(), sd[f"pts_linears.{i}.bias"].copy()]
+    for name in ("feature_linear", "views_linears.0", "rgb_linear", "alpha_linear"):
+        keras += [sd[name + ".weight"].T.copy(), sd[name + ".bias"].copy()]
+    net = N.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, use_viewdirs=True).load_weights_from_keras(keras)
+    g = load_golden("mlp_forward")
+    out = cpu(net(gpu(g["embedded"])))
+    assert np.abs(out - g["out"]).max() <= 3e-6 * max(1.0, np.abs(g["out"]).max())
