@@ -427,6 +427,39 @@ def gold_train():
     save("train_step", rays=n(rays), target=n(target), **out)
 
 
+def gold_llff_pose_math():
+    """The pure-numpy pose functions of nerf/load_llff.py, executed from its source (the module itself
+    cannot be imported here: it needs imageio). Only function definitions that touch numpy alone are
+    exec'd; inputs are seeded synthetic forward-facing poses in the poses_bounds.npy convention."""
+    import ast
+    src = open(os.path.join(REF, "load_llff.py")).read()
+    tree = ast.parse(src)
+    want = {"normalize", "viewmatrix", "ptstocam", "poses_avg", "render_path_spiral", "recenter_poses",
+            "spherify_poses"}
+    mod = ast.Module(body=[nd for nd in tree.body if isinstance(nd, ast.FunctionDef) and nd.name in want],
+                     type_ignores=[])
+    ns = {"np": np}
+    exec(compile(mod, "load_llff.py", "exec"), ns)
+    rs = np.random.RandomState(107)
+    n_img = 9
+    poses = np.zeros((n_img, 3, 5), np.float32)
+    for i in range(n_img):
+        ang = rs.normal(0, 0.08, 3)
+        Rx = np.array([[1, 0, 0], [0, np.cos(ang[0]), -np.sin(ang[0])], [0, np.sin(ang[0]), np.cos(ang[0])]])
+        Ry = np.array([[np.cos(ang[1]), 0, np.sin(ang[1])], [0, 1, 0], [-np.sin(ang[1]), 0, np.cos(ang[1])]])
+        poses[i, :, :3] = (Rx @ Ry).astype(np.float32)
+        poses[i, :, 3] = rs.normal(0, 0.4, 3) + np.array([0, 0, 0.2 * i])
+        poses[i, :, 4] = [378, 504, 407.5]
+    bds = np.stack([rs.uniform(1.0, 1.5, n_img), rs.uniform(8, 12, n_img)], -1).astype(np.float32)
+    rec = ns["recenter_poses"](poses.copy())
+    avg = ns["poses_avg"](rec)
+    up = ns["normalize"](rec[:, :3, 1].sum(0))
+    spiral = np.array(ns["render_path_spiral"](avg, up, np.array([0.3, 0.2, 0.1]), 3.0, 0.2, zrate=.5, rots=2, N=12))
+    sp_poses, sp_render, sp_bds = ns["spherify_poses"](rec.copy(), bds.copy())
+    save("llff_pose_math", poses=poses, bds=bds, recentered=rec, avg=avg, spiral=spiral, sph_poses=sp_poses,
+         sph_render=sp_render, sph_bds=sp_bds)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -441,3 +474,4 @@ if __name__ == "__main__":
     gold_ray_packing()
     gold_metrics()
     gold_train()
+    gold_llff_pose_math()
