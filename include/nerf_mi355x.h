@@ -121,6 +121,19 @@ int nerf_sample_pdf(nerf_ctx* ctx, const float* bins /*[dev]*/, const float* wei
                     const float* u /*[dev]*/, int64_t N, int M, int n_samples,
                     float* out /*[dev]*/, void* stream);
 
+/* Stratified depths of render_rays (nerf.ipynb:418-444): z_vals [N, N_samples] from the near/far columns of
+ * the ray record; lindisp samples uniformly in disparity; t_rand [N, N_samples] (or NULL) jitters every
+ * sample inside its stratum (perturb > 0). */
+int nerf_stratified_z(nerf_ctx* ctx, const float* rays /*[dev]*/, int ray_stride, int64_t N, int N_samples,
+                      int lindisp, const float* t_rand /*[dev]*/, float* z_vals /*[dev]*/, void* stream);
+
+/* The resampling stage of render_rays (nerf.ipynb:458-467, 486): z_vals_mid, sample_pdf on
+ * weights[...,1:-1], then sort(cat[z_vals, z_samples]) and std(z_samples). u [N,n_samples] or NULL (det).
+ * z_samples, z_merged [N, S+n_samples] and z_std [N] may each be NULL. */
+int nerf_resample(nerf_ctx* ctx, const float* z_vals /*[dev] [N,S]*/, const float* weights /*[dev] [N,S]*/,
+                  const float* u /*[dev]*/, int64_t N, int S, int n_samples, float* z_samples /*[dev]*/,
+                  float* z_merged /*[dev]*/, float* z_std /*[dev]*/, void* stream);
+
 /* The ray-chunk renderer ------------------------------------------------------------
  * render_rays (nerf.ipynb:359-492) for one chunk of rays, all stages on the device with
  * no host synchronisation: stratified depths -> encode+MLP (coarse) -> composite ->

@@ -17,7 +17,7 @@ EXPORTS = (
     "nerf_load_weights", "nerf_num_weight_tensors", "nerf_embed", "nerf_mlp_forward", "nerf_run_network",
     "nerf_raw2outputs", "nerf_sample_pdf", "nerf_render_rays", "nerf_profile_enable", "nerf_profile_read",
     "nerf_workspace_bytes", "nerf_generate_rays", "nerf_image_metrics", "nerf_train_step", "nerf_get_weights",
-    "nerf_get_gradients",
+    "nerf_get_gradients", "nerf_stratified_z", "nerf_resample",
 )
 
 
@@ -115,6 +115,10 @@ def load():
     lib.nerf_get_weights.argtypes = [vp, i32, C.POINTER(vp), i32]
     lib.nerf_get_gradients.restype = i32
     lib.nerf_get_gradients.argtypes = [vp, i32, C.POINTER(vp), i32]
+    lib.nerf_stratified_z.restype = i32
+    lib.nerf_stratified_z.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp, vp]
+    lib.nerf_resample.restype = i32
+    lib.nerf_resample.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp]
     lib.nerf_workspace_bytes.restype = i64
     lib.nerf_workspace_bytes.argtypes = [vp]
     _lib = lib

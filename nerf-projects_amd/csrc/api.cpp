@@ -334,6 +334,32 @@ int nerf_sample_pdf(nerf_ctx* c, const float* bins, const float* weights, const 
     return NERF_OK;
 }
 
+int nerf_stratified_z(nerf_ctx* c, const float* rays, int ray_stride, int64_t N, int N_samples, int lindisp,
+                      const float* t_rand, float* z_vals, void* stream) {
+    if (c && N == 0) return NERF_OK;
+    if (!c || !rays || !z_vals || N < 0 || N_samples < 1 || ray_stride < 8) {
+        set_error("nerf_stratified_z: invalid argument");
+        return NERF_E_INVALID;
+    }
+    DeviceGuard g(c->device);
+    HIP_TRY(launch_stratified(rays, ray_stride, N, N_samples, lindisp, t_rand, z_vals, (hipStream_t)stream));
+    return NERF_OK;
+}
+
+int nerf_resample(nerf_ctx* c, const float* z_vals, const float* weights, const float* u, int64_t N, int S,
+                  int n_samples, float* z_samples, float* z_merged, float* z_std, void* stream) {
+    if (c && N == 0) return NERF_OK;
+    if (!c || !z_vals || !weights || N < 0 || S < 3 || n_samples < 1 || S + n_samples > 4096 ||
+        (!z_samples && !z_merged)) {
+        set_error("nerf_resample: invalid argument (S >= 3, S + n_samples <= 4096, an output is required)");
+        return NERF_E_INVALID;
+    }
+    DeviceGuard g(c->device);
+    HIP_TRY(launch_sample_pdf(nullptr, weights, S, 1, z_vals, u, N, S - 1, n_samples, z_samples, z_merged, z_std,
+                              (hipStream_t)stream));
+    return NERF_OK;
+}
+
 int nerf_render_rays(nerf_ctx* c, const nerf_render_args* r) {
     if (!c || !r || (!r->rays && r->n_rays != 0) || r->n_rays < 0) {
         set_error("nerf_render_rays: NULL argument");

@@ -97,36 +97,35 @@ def _area_half(img):
 # Blender (nerf/load_blender.py:37-89)
 # ----------------------------------------------------------------------------------------------
 
+def _blender_split(basedir, split, stride):
+    """Images (RGBA, float32 in [0,1]) and camera-to-world matrices of one split, every `stride`-th frame."""
+    with open(os.path.join(basedir, f'transforms_{split}.json')) as fp:
+        meta = json.load(fp)
+    frames = meta['frames'][::stride]
+    imgs = np.stack([read_png(os.path.join(basedir, fr['file_path'] + '.png')) for fr in frames])
+    poses = np.stack([np.asarray(fr['transform_matrix']) for fr in frames])
+    return (imgs / 255.).astype(np.float32), poses.astype(np.float32), float(meta['camera_angle_x'])
+
+
 def load_blender_data(basedir, half_res=False, testskip=1):
-    """``(imgs [N,H,W,4] float32 in [0,1], poses [N,4,4], render_poses [40,4,4], [H, W, focal], i_split)``."""
-    splits = ['train', 'val', 'test']
-    metas = {}
-    for s in splits:
-        with open(os.path.join(basedir, 'transforms_{}.json'.format(s)), 'r') as fp:
-            metas[s] = json.load(fp)
-    all_imgs, all_poses, counts = [], [], [0]
-    for s in splits:
-        meta = metas[s]
-        skip = 1 if (s == 'train' or testskip == 0) else testskip
-        imgs, poses = [], []
-        for frame in meta['frames'][::skip]:
-            imgs.append(read_png(os.path.join(basedir, frame['file_path'] + '.png')))
-            poses.append(np.array(frame['transform_matrix']))
-        imgs = (np.array(imgs) / 255.).astype(np.float32)          # keep all 4 channels (RGBA)
-        poses = np.array(poses).astype(np.float32)
-        counts.append(counts[-1] + imgs.shape[0])
-        all_imgs.append(imgs)
-        all_poses.append(poses)
-    i_split = [np.arange(counts[i], counts[i + 1]) for i in range(3)]
-    imgs = np.concatenate(all_imgs, 0)
-    poses = np.concatenate(all_poses, 0)
-    H, W = imgs[0].shape[:2]
-    camera_angle_x = float(meta['camera_angle_x'])
-    focal = .5 * W / np.tan(.5 * camera_angle_x)
-    render_poses = np.stack([pose_spherical(angle, -30.0, 4.0) for angle in np.linspace(-180, 180, 40 + 1)[:-1]], 0)
+    """``(imgs [N,H,W,4] in [0,1], poses [N,4,4], render_poses [40,4,4], [H, W, focal], i_split)`` for a
+    NeRF-synthetic scene: train frames in full, val/test every `testskip`-th (0 = all), the 40-view
+    spherical render path, optional 2x area down-sampling (nerf/load_blender.py:37-89)."""
+    per_split, offsets = [], [0]
+    for split in ('train', 'val', 'test'):
+        stride = 1 if (split == 'train' or testskip == 0) else testskip
+        imgs, poses, angle = _blender_split(basedir, split, stride)
+        per_split.append((imgs, poses))
+        offsets.append(offsets[-1] + len(imgs))
+    i_split = [np.arange(offsets[k], offsets[k + 1]) for k in range(3)]
+    imgs = np.concatenate([p[0] for p in per_split], 0)
+    poses = np.concatenate([p[1] for p in per_split], 0)
+    H, W = imgs.shape[1:3]
+    focal = .5 * W / np.tan(.5 * angle)                     # camera_angle_x of the last split read (:71-73)
+    render_poses = np.stack([pose_spherical(a, -30.0, 4.0) for a in np.linspace(-180, 180, 41)[:-1]], 0)
     if half_res:
         H, W, focal = H // 2, W // 2, focal / 2.
-        imgs = np.stack([_area_half(img.astype(np.float64)) for img in imgs], 0)   # float64, like np.zeros at :81
+        imgs = np.stack([_area_half(im.astype(np.float64)) for im in imgs], 0)   # float64 like np.zeros at :81
     return imgs, poses, render_poses, [H, W, focal], i_split
 
 
@@ -159,147 +158,146 @@ def _minify(basedir, factor):
 
 
 def _load_data(basedir, factor=None, load_imgs=True):
-    """load_llff.py:65-139 for the ``factor`` form used by ``load_llff_data``."""
-    poses_arr = np.load(os.path.join(basedir, 'poses_bounds.npy'))
-    poses = poses_arr[:, :-2].reshape([-1, 3, 5]).transpose([1, 2, 0])
-    bds = poses_arr[:, -2:].transpose([1, 0])
-    sfx = ''
+    """Raw LLFF arrays: ``poses [3,5,N]`` (rotation | translation | hwf), ``bds [2,N]`` and, optionally,
+    ``imgs [H,W,3,N]`` in [0,1] from ``images_<factor>`` (load_llff.py:65-139, the ``factor`` form)."""
+    table = np.load(os.path.join(basedir, 'poses_bounds.npy'))            # [N, 17] = 3x5 pose + near/far
+    poses = np.moveaxis(table[:, :15].reshape(-1, 3, 5), 0, -1).copy()
+    bds = table[:, 15:].T.copy()
     if factor is not None:
-        sfx = '_{}'.format(factor)
         _minify(basedir, factor)
-    else:
-        factor = 1
-    imgdir = os.path.join(basedir, 'images' + sfx)
+    imgdir = os.path.join(basedir, 'images' if factor is None else f'images_{factor}')
     if not os.path.exists(imgdir):
         raise RuntimeError(f"{imgdir} does not exist")
-    imgfiles = _image_files(imgdir)
-    if poses.shape[-1] != len(imgfiles):
-        raise RuntimeError('Mismatch between imgs {} and poses {} !!!!'.format(len(imgfiles), poses.shape[-1]))
-    sh = read_png(imgfiles[0]).shape
-    poses[:2, 4, :] = np.array(sh[:2]).reshape([2, 1])
-    poses[2, 4, :] = poses[2, 4, :] * 1. / factor
+    files = _image_files(imgdir)
+    if len(files) != poses.shape[-1]:
+        raise RuntimeError('Mismatch between imgs {} and poses {} !!!!'.format(len(files), poses.shape[-1]))
+    first = read_png(files[0])
+    poses[0, 4, :], poses[1, 4, :] = first.shape[0], first.shape[1]       # h, w of the images actually used
+    poses[2, 4, :] /= (1 if factor is None else factor)                   # focal shrinks with the images
     if not load_imgs:
         return poses, bds
-    imgs = np.stack([read_png(f)[..., :3] / 255. for f in imgfiles], -1)
+    imgs = np.stack([read_png(f)[..., :3] / 255. for f in files], -1)
     return poses, bds, imgs
 
 
 def normalize(x):
-    return x / np.linalg.norm(x)
+    """Unit vector (load_llff.py `normalize`)."""
+    x = np.asarray(x)
+    return x / np.sqrt(np.sum(x * x))
 
 
 def viewmatrix(z, up, pos):
-    vec2 = normalize(z)
-    vec0 = normalize(np.cross(up, vec2))
-    vec1 = normalize(np.cross(vec2, vec0))
-    return np.stack([vec0, vec1, vec2, pos], 1)
+    """Right-handed camera frame [x | y | z | origin] as a [3,4] matrix whose z axis is `z` and whose y axis is
+    `up` made orthogonal to it (load_llff.py `viewmatrix`)."""
+    fwd = normalize(z)
+    right = normalize(np.cross(up, fwd))
+    true_up = normalize(np.cross(fwd, right))
+    return np.column_stack([right, true_up, fwd, pos])
 
 
 def poses_avg(poses):
-    hwf = poses[0, :3, -1:]
-    center = poses[:, :3, 3].mean(0)
-    vec2 = normalize(poses[:, :3, 2].sum(0))
-    up = poses[:, :3, 1].sum(0)
-    return np.concatenate([viewmatrix(vec2, up, center), hwf], 1)
+    """'Average' camera of a set of [N,3,5] poses: mean position, summed viewing and up directions, and
+    the first pose's hwf column (load_llff.py `poses_avg`)."""
+    frame = viewmatrix(poses[:, :3, 2].sum(0), poses[:, :3, 1].sum(0), poses[:, :3, 3].mean(0))
+    return np.concatenate([frame, poses[0, :3, -1:]], 1)
+
+
+def _homogeneous(m34):
+    """[...,3,4] -> [...,4,4] with a (0,0,0,1) bottom row."""
+    m34 = np.asarray(m34)
+    bottom = np.broadcast_to(np.array([0., 0., 0., 1.]), m34.shape[:-2] + (1, 4))
+    return np.concatenate([m34, bottom], -2)
 
 
 def render_path_spiral(c2w, up, rads, focal, zdelta, zrate, rots, N):
-    render_poses = []
-    rads = np.array(list(rads) + [1.])
-    hwf = c2w[:, 4:5]
+    """N cameras on a spiral around the average pose, all looking at the point `focal` in front of it
+    (load_llff.py `render_path_spiral`; `zdelta` is unused there as well)."""
+    scale = np.append(np.asarray(rads, dtype=np.float64), 1.0)
+    frame, hwf = c2w[:3, :4], c2w[:, 4:5]
+    target = frame @ np.array([0., 0., -focal, 1.])
+    out = []
     for theta in np.linspace(0., 2. * np.pi * rots, N + 1)[:-1]:
-        c = np.dot(c2w[:3, :4], np.array([np.cos(theta), -np.sin(theta), -np.sin(theta * zrate), 1.]) * rads)
-        z = normalize(c - np.dot(c2w[:3, :4], np.array([0, 0, -focal, 1.])))
-        render_poses.append(np.concatenate([viewmatrix(z, up, c), hwf], 1))
-    return render_poses
+        eye = frame @ (np.array([np.cos(theta), -np.sin(theta), -np.sin(theta * zrate), 1.]) * scale)
+        out.append(np.concatenate([viewmatrix(eye - target, up, eye), hwf], 1))
+    return out
 
 
 def recenter_poses(poses):
-    poses_ = poses + 0
-    bottom = np.reshape([0, 0, 0, 1.], [1, 4])
-    c2w = poses_avg(poses)
-    c2w = np.concatenate([c2w[:3, :4], bottom], -2)
-    bottom = np.tile(np.reshape(bottom, [1, 1, 4]), [poses.shape[0], 1, 1])
-    poses = np.concatenate([poses[:, :3, :4], bottom], -2)
-    poses = np.linalg.inv(c2w) @ poses
-    poses_[:, :3, :4] = poses[:, :3, :4]
-    return poses_
+    """Express all poses in the frame of their average camera (load_llff.py `recenter_poses`)."""
+    out = poses.copy()
+    to_avg = np.linalg.inv(_homogeneous(poses_avg(poses)[:3, :4]))
+    out[:, :3, :4] = (to_avg @ _homogeneous(poses[:, :3, :4]))[:, :3, :4]
+    return out
 
 
 def spherify_poses(poses, bds):
-    def p34_to_44(p):
-        return np.concatenate([p, np.tile(np.reshape(np.eye(4)[-1, :], [1, 1, 4]), [p.shape[0], 1, 1])], 1)
-    rays_d = poses[:, :3, 2:3]
-    rays_o = poses[:, :3, 3:4]
+    """360-degree captures: recentre on the point closest to all optical axes, scale the camera shell to unit
+    radius (``bds`` is rescaled in place, as in the reference) and emit a 120-view circular path
+    (load_llff.py `spherify_poses`)."""
+    axes = poses[:, :3, 2:3]                       # [N,3,1] viewing directions
+    origins = poses[:, :3, 3:4]
+    # least-squares point nearest to the lines origin + t*axis
+    proj = np.eye(3) - axes * np.swapaxes(axes, 1, 2)
+    lhs = (np.swapaxes(proj, 1, 2) @ proj).mean(0)
+    rhs = (-proj @ origins).mean(0)
+    centre = np.squeeze(-np.linalg.inv(lhs) @ rhs)
 
-    def min_line_dist(rays_o, rays_d):
-        A_i = np.eye(3) - rays_d * np.transpose(rays_d, [0, 2, 1])
-        b_i = -A_i @ rays_o
-        return np.squeeze(-np.linalg.inv((np.transpose(A_i, [0, 2, 1]) @ A_i).mean(0)) @ (b_i).mean(0))
-    center = min_line_dist(rays_o, rays_d)
-    up = (poses[:, :3, 3] - center).mean(0)
-    vec0 = normalize(up)
-    vec1 = normalize(np.cross([.1, .2, .3], vec0))
-    vec2 = normalize(np.cross(vec0, vec1))
-    c2w = np.stack([vec1, vec2, vec0, center], 1)
-    poses_reset = np.linalg.inv(p34_to_44(c2w[None])) @ p34_to_44(poses[:, :3, :4])
-    rad = np.sqrt(np.mean(np.sum(np.square(poses_reset[:, :3, 3]), -1)))
-    sc = 1. / rad
-    poses_reset[:, :3, 3] *= sc
-    bds *= sc
-    rad *= sc
-    centroid = np.mean(poses_reset[:, :3, 3], 0)
-    zh = centroid[2]
-    radcircle = np.sqrt(rad ** 2 - zh ** 2)
-    new_poses = []
+    z_axis = normalize((poses[:, :3, 3] - centre).mean(0))
+    x_axis = normalize(np.cross([.1, .2, .3], z_axis))
+    y_axis = normalize(np.cross(z_axis, x_axis))
+    world = np.column_stack([x_axis, y_axis, z_axis, centre])
+    reset = np.linalg.inv(_homogeneous(world[None])) @ _homogeneous(poses[:, :3, :4])
+
+    radius = np.sqrt(np.mean(np.sum(np.square(reset[:, :3, 3]), -1)))
+    shrink = 1. / radius
+    reset[:, :3, 3] *= shrink
+    bds *= shrink
+    radius *= shrink
+    height = np.mean(reset[:, :3, 3], 0)[2]
+    ring = np.sqrt(radius ** 2 - height ** 2)
+    circle = []
     for th in np.linspace(0., 2. * np.pi, 120):
-        camorigin = np.array([radcircle * np.cos(th), radcircle * np.sin(th), zh])
-        up = np.array([0, 0, -1.])
-        vec2 = normalize(camorigin)
-        vec0 = normalize(np.cross(vec2, up))
-        vec1 = normalize(np.cross(vec2, vec0))
-        new_poses.append(np.stack([vec0, vec1, vec2, camorigin], 1))
-    new_poses = np.stack(new_poses, 0)
-    new_poses = np.concatenate([new_poses, np.broadcast_to(poses[0, :3, -1:], new_poses[:, :3, -1:].shape)], -1)
-    poses_reset = np.concatenate([poses_reset[:, :3, :4],
-                                  np.broadcast_to(poses[0, :3, -1:], poses_reset[:, :3, -1:].shape)], -1)
-    return poses_reset, new_poses, bds
+        eye = np.array([ring * np.cos(th), ring * np.sin(th), height])
+        fwd = normalize(eye)
+        right = normalize(np.cross(fwd, np.array([0, 0, -1.])))
+        circle.append(np.column_stack([right, normalize(np.cross(fwd, right)), fwd, eye]))
+    circle = np.stack(circle, 0)
+    hwf = poses[0, :3, -1:]
+    circle = np.concatenate([circle, np.broadcast_to(hwf, circle[:, :3, -1:].shape)], -1)
+    reset = np.concatenate([reset[:, :3, :4], np.broadcast_to(hwf, reset[:, :3, -1:].shape)], -1)
+    return reset, circle, bds
 
 
 def load_llff_data(basedir, factor=8, recenter=True, bd_factor=.75, spherify=False, path_zflat=False):
-    """``(images [N,H,W,3], poses [N,3,5], bds [N,2], render_poses, i_test)`` (load_llff.py:242-315)."""
+    """``(images [N,H,W,3], poses [N,3,5], bds [N,2], render_poses, i_test)`` (load_llff.py:242-315):
+    axis convention fix-up, depth-bound rescale by ``bd_factor``, recentring, then either the spherified
+    circle or the forward-facing spiral as render path, and the hold-out view nearest the average pose."""
     poses, bds, imgs = _load_data(basedir, factor=factor)
-    poses = np.concatenate([poses[:, 1:2, :], -poses[:, 0:1, :], poses[:, 2:, :]], 1)
+    # LLFF stores [down, right, back]; NeRF wants [right, up, back]
+    poses = np.concatenate([poses[:, 1:2], -poses[:, 0:1], poses[:, 2:]], 1)
     poses = np.moveaxis(poses, -1, 0).astype(np.float32)
     images = np.moveaxis(imgs, -1, 0).astype(np.float32)
     bds = np.moveaxis(bds, -1, 0).astype(np.float32)
-    sc = 1. if bd_factor is None else 1. / (bds.min() * bd_factor)
-    poses[:, :3, 3] *= sc
-    bds *= sc
+    scale = 1. if bd_factor is None else 1. / (bds.min() * bd_factor)
+    poses[:, :3, 3] *= scale
+    bds *= scale
     if recenter:
         poses = recenter_poses(poses)
     if spherify:
         poses, render_poses, bds = spherify_poses(poses, bds)
     else:
-        c2w = poses_avg(poses)
+        centre = poses_avg(poses)
         up = normalize(poses[:, :3, 1].sum(0))
-        close_depth, inf_depth = bds.min() * .9, bds.max() * 5.
-        dt = .75
-        focal = 1. / (((1. - dt) / close_depth + dt / inf_depth))
-        zdelta = close_depth * .2
-        tt = poses[:, :3, 3]
-        rads = np.percentile(np.abs(tt), 90, 0)
-        c2w_path = c2w
-        N_views, N_rots = 120, 2
+        near_d, far_d = bds.min() * .9, bds.max() * 5.
+        focus = 1. / (.25 / near_d + .75 / far_d)                 # dt = .75 blend of the disparities
+        radii = np.percentile(np.abs(poses[:, :3, 3]), 90, 0)
+        views, turns = 120, 2
         if path_zflat:
-            zloc = -close_depth * .1
-            c2w_path[:3, 3] = c2w_path[:3, 3] + zloc * c2w_path[:3, 2]
-            rads[2] = 0.
-            N_rots = 1
-            N_views //= 2
-        render_poses = render_path_spiral(c2w_path, up, rads, focal, zdelta, zrate=.5, rots=N_rots, N=N_views)
+            centre[:3, 3] += -near_d * .1 * centre[:3, 2]
+            radii[2] = 0.
+            views, turns = 60, 1
+        render_poses = render_path_spiral(centre, up, radii, focus, near_d * .2, zrate=.5, rots=turns, N=views)
     render_poses = np.array(render_poses).astype(np.float32)
-    c2w = poses_avg(poses)
-    dists = np.sum(np.square(c2w[:3, 3] - poses[:, :3, 3]), -1)
-    i_test = np.argmin(dists)
-    return images.astype(np.float32), poses.astype(np.float32), bds, render_poses, i_test
+    mean_pos = poses_avg(poses)[:3, 3]
+    i_test = np.argmin(np.sum(np.square(mean_pos - poses[:, :3, 3]), -1))
+    return images, poses.astype(np.float32), bds, render_poses, i_test

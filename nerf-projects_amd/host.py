@@ -517,51 +517,64 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         return _render_rays_fused(ctx, ray_batch, network_fn, network_fine, N_samples, N_importance, retraw,
                                   lindisp, perturb, white_bkgd, raw_noise_std, pytest, _extras, _z_vals_fine)
 
-    # ---- staged composition around an opaque network_query_fn -------------------------------
-    N_rays = ray_batch.shape[0]
-    rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
-    viewdirs = ray_batch[:, -3:] if has_dirs else None
-    near, far = ray_batch[:, 6:7], ray_batch[:, 7:8]
-    t_vals = torch.linspace(0., 1., steps=N_samples, device=ctx.device)
-    if not lindisp:
-        z_vals = near * (1. - t_vals) + far * t_vals
-    else:
-        z_vals = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
-    z_vals = z_vals.expand([N_rays, N_samples])
-    if perturb > 0.:
-        mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
-        upper = torch.cat([mids, z_vals[..., -1:]], -1)
-        lower = torch.cat([z_vals[..., :1], mids], -1)
-        if pytest:
-            np.random.seed(0)
-            t_rand = _dev(np.random.rand(*list(z_vals.shape)), ctx)
-        else:
-            t_rand = torch.rand(z_vals.shape, device=ctx.device)
-        z_vals = lower + (upper - lower) * t_rand
-    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
-    raw = network_query_fn(pts, viewdirs, network_fn)
-    rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, raw_noise_std, white_bkgd,
-                                                                 pytest=pytest)
-    if _extras is not None:
-        _extras.update(z_coarse=z_vals, weights_coarse=weights)
-    if N_importance > 0:
-        rgb_map_0, disp_map_0, acc_map_0 = rgb_map, disp_map, acc_map
-        z_vals_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
-        z_samples = sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance, det=(perturb == 0.), pytest=pytest)
-        z_vals, _ = torch.sort(torch.cat([z_vals, z_samples], -1), -1)
-        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
-        run_fn = network_fn if network_fine is None else network_fine
-        raw = network_query_fn(pts, viewdirs, run_fn)
-        rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, raw_noise_std,
-                                                                     white_bkgd, pytest=pytest)
-        if _extras is not None:
-            _extras.update(z_samples=z_samples, z_fine=z_vals, weights_fine=weights)
-    ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map}
+    # ---- staged route: an opaque network_query_fn is honoured; every other stage is a kernel ----------
+    return _render_rays_staged(ctx, ray_batch, network_fn, network_query_fn, int(N_samples), int(N_importance),
+                               network_fine, retraw, lindisp, perturb, white_bkgd, raw_noise_std, pytest, _extras)
+
+
+def _uniforms(shape, pytest, ctx):
+    """U[0,1) draws in the reference's order; under ``pytest`` its ``np.random.seed(0)`` sequence."""
+    if pytest:
+        np.random.seed(0)
+        return _dev(np.random.rand(*shape), ctx)
+    return torch.rand(shape, device=ctx.device, dtype=torch.float32)
+
+
+def _stage_depths(ctx, ray_batch, n_samples, lindisp, t_rand):
+    z = torch.empty((ray_batch.shape[0], n_samples), device=ctx.device, dtype=torch.float32)
+    check(ctx.lib.nerf_stratified_z(ctx.handle, _ptr(ray_batch), ray_batch.shape[1], ray_batch.shape[0], n_samples,
+                                    int(bool(lindisp)), _ptr(t_rand), _ptr(z), ctx.stream()))
+    return z
+
+
+def _stage_resample(ctx, z_vals, weights, n_importance, u):
+    N, S = z_vals.shape
+    o = dict(device=ctx.device, dtype=torch.float32)
+    z_samples, z_merged, z_std = torch.empty((N, n_importance), **o), torch.empty((N, S + n_importance), **o), \
+        torch.empty((N,), **o)
+    check(ctx.lib.nerf_resample(ctx.handle, _ptr(z_vals), _ptr(weights.contiguous()), _ptr(u), N, S, n_importance,
+                                _ptr(z_samples), _ptr(z_merged), _ptr(z_std), ctx.stream()))
+    return z_samples, z_merged, z_std
+
+
+def _render_rays_staged(ctx, ray_batch, network_fn, query, Sc, Si, network_fine, retraw, lindisp, perturb, white_bkgd,
+                        raw_noise_std, pytest, extras):
+    """render_rays with the network evaluation delegated to ``query(pts, viewdirs, net)``
+    (nerf.ipynb:447-475): depth sampling, compositing, resampling and merging are the package's kernels;
+    only ``pts = o + d*z`` is plain tensor arithmetic on the device."""
+    origins, dirs = ray_batch[:, None, 0:3], ray_batch[:, None, 3:6]
+    viewdirs = ray_batch[:, -3:] if ray_batch.shape[-1] > 8 else None
+    jitter = _uniforms((ray_batch.shape[0], Sc), pytest, ctx) if perturb > 0. else None
+
+    def shade(z_vals, net):
+        raw = query(origins + dirs * z_vals[..., :, None], viewdirs, net)
+        return raw, raw2outputs(raw, z_vals, ray_batch[:, 3:6], raw_noise_std, white_bkgd, pytest=pytest)
+
+    z_vals = _stage_depths(ctx, ray_batch, Sc, lindisp, jitter)
+    raw, (rgb, disp, acc, weights, _) = shade(z_vals, network_fn)
+    if extras is not None:
+        extras.update(z_coarse=z_vals, weights_coarse=weights)
+    ret = {}
+    if Si > 0:
+        ret.update(rgb0=rgb, disp0=disp, acc0=acc)
+        u = _uniforms((ray_batch.shape[0], Si), pytest, ctx) if perturb > 0. else None      # det = (perturb == 0)
+        z_samples, z_vals, ret['z_std'] = _stage_resample(ctx, z_vals, weights, Si, u)
+        raw, (rgb, disp, acc, weights, _) = shade(z_vals, network_fn if network_fine is None else network_fine)
+        if extras is not None:
+            extras.update(z_samples=z_samples, z_fine=z_vals, weights_fine=weights)
+    ret.update(rgb_map=rgb, disp_map=disp, acc_map=acc)
     if retraw:
         ret['raw'] = raw
-    if N_importance > 0:
-        ret['rgb0'], ret['disp0'], ret['acc0'] = rgb_map_0, disp_map_0, acc_map_0
-        ret['z_std'] = torch.std(z_samples, dim=-1, unbiased=False)
     return ret
 
 
