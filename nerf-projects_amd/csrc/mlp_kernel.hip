@@ -126,16 +126,13 @@ struct Range {
 //
 // The barrier follows step NSTEP/2-1 (see Pipe); the 8 LDS-DMA issues of chunk c+2 come right
 // after it.
-#ifndef NERF_MLP_SYNC_VARIANT
-#define NERF_MLP_SYNC_VARIANT 1
-#endif
 template <int S, int NSTEP, class Body>
 __device__ __forceinline__ void run_steps(Pipe& p, Frag16& cur, const f32x4* fr, const f32x4* fr_next, Body& body) {
     if constexpr (S < NSTEP) {
         Frag16 nxt = (S + 1 < NSTEP) ? read_frags(fr, (S + 1) * 4) : read_frags(fr_next, 0);
         body(StepTag<S>{}, Range<0, 16>{}, cur);
-#if NERF_MLP_SYNC_VARIANT == 1
         if constexpr (S == NSTEP / 2) {
+            // the step after the barrier also issues the 8 LDS-DMA pieces of chunk c+2, one per MFMA
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
@@ -147,9 +144,6 @@ __device__ __forceinline__ void run_steps(Pipe& p, Frag16& cur, const f32x4* fr,
         } else {
             SCHED_STEP();
         }
-#else
-        SCHED_STEP();
-#endif
         cur = nxt;
         if constexpr (S == NSTEP / 2 - 1) {
             // keep the step's 15 trailing MFMAs above the barrier: the reads issued before them have
@@ -159,10 +153,7 @@ __device__ __forceinline__ void run_steps(Pipe& p, Frag16& cur, const f32x4* fr,
             __syncthreads();
 #endif
             const int nx = p.c + 2 < p.n ? p.c + 2 : p.c + 2 - p.n;   // wraps into the next tile's stream
-            prefetch_chunk(p, nx, ring_next(p.b, 2));
-#if NERF_MLP_SYNC_VARIANT == 0
-            __builtin_amdgcn_sched_barrier(0);
-#endif
+            prefetch_chunk(p, nx, ring_next(p.b, 2));   // scheduled among the next step's MFMAs
         }
         run_steps<S + 1, NSTEP>(p, cur, fr, fr_next, body);
     }
