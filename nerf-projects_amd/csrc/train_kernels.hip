@@ -26,15 +26,40 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Both GEMMs keep their LDS tiles K-contiguous per row ([row][32 k + 4 pad]) so that an MFMA operand
+// fragment - 16 k-steps of one row - is four ds_read_b128 (conflict-free: bank = 36*row mod 64), and they
+// software-pipeline those reads by hand like the inference kernel: the fragment of step n+1 is requested
+// right after the first MFMA of step n (one wave per SIMD has nothing else to hide LDS latency behind).
+// k-step t of an MFMA contracts index 16*h + t of the tile for lane half h; A and B use the same order.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLd = 36;
+
+struct F16 {
+    f32x4 q[4];
+};
+__device__ __forceinline__ F16 frag_at(const float* tile, int row, int h) {
+    F16 f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f.q[q] = *(const f32x4*)&tile[row * kLd + 16 * h + 4 * q];
+    return f;
+}
+__device__ __forceinline__ void mma_frag(f32x16& acc, const F16& a, const F16& b) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc = mfma32(a.q[t >> 2][t & 3], b.q[t >> 2][t & 3], acc);
+}
+#define SCHED_FRAG_STEP()                                     \
+    do {                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 15, 0);   \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
 // C[M,N] = A[M,K] * B[K,N]      (N <= 256, any K; one workgroup = 128 rows x all N columns)
 // ---------------------------------------------------------------------------------------------
-constexpr int kAsLd = 36;   // 32 + 4 pad: ds_read_b128 of 32 rows is conflict-free (bank = 36*i mod 64)
-
-// The next k-tile's global loads are issued into registers before the current tile's MFMAs and
-// written to LDS after them (global latency hides under 128 MFMAs per wave).
 __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmRows g) {
-    __shared__ __attribute__((aligned(16))) float As[128 * kAsLd];
-    __shared__ __attribute__((aligned(16))) float Bs[32 * 256];
+    __shared__ __attribute__((aligned(16))) float As[128 * kLd];   // [row of A][k]
+    __shared__ __attribute__((aligned(16))) float Bs[256 * kLd];   // [column of B][k]  (transposed while staging)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
     const int64_t row0 = (int64_t)blockIdx.x * 128;
     const int n_ct = (g.N + 31) >> 5;   // column tiles in use (<= 8), uniform
@@ -45,8 +70,9 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmRows g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
 
+    // global -> registers (issued one k-tile ahead) -> LDS
     float ra[16], rb[32];
-    auto load_tile = [&](int k0) {   // A[128 x 32] and B[32 x 256], zero filled outside; coalesced along rows
+    auto load_tile = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int e = it * 256 + tid, r = e >> 5, c = e & 31;
@@ -61,10 +87,13 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmRows g) {
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int e = it * 256 + tid;
-            As[(e >> 5) * kAsLd + (e & 31)] = ra[it];
+            As[(e >> 5) * kLd + (e & 31)] = ra[it];
         }
 #pragma unroll
-        for (int it = 0; it < 32; ++it) Bs[it * 256 + tid] = rb[it];
+        for (int q = 0; q < 8; ++q) {   // thread = column n: its 32 k values, 16 bytes at a time
+            f32x4 v = {rb[4 * q], rb[4 * q + 1], rb[4 * q + 2], rb[4 * q + 3]};
+            *(f32x4*)&Bs[tid * kLd + 4 * q] = v;
+        }
     };
 
     load_tile(0);
@@ -73,16 +102,17 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmRows g) {
     for (int k0 = 0; k0 < g.K; k0 += 32) {
         const bool more = k0 + 32 < g.K;
         if (more) load_tile(k0 + 32);
-        // lane (i = j, h) owns A[row 32*wave + i][k = 16h + t], t = 0..15 (any k order works as long as B agrees)
-        f32x4 a4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a4[q] = *(const f32x4*)&As[(32 * wave + j) * kAsLd + 16 * h + 4 * q];
+        const F16 a = frag_at(As, 32 * wave + j, h);
+        F16 cur = frag_at(Bs, j, h);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             if (c < n_ct) {
-#pragma unroll
-                for (int t = 0; t < 16; ++t)
-                    acc[c] = mfma32(a4[t >> 2][t & 3], Bs[(16 * h + t) * 256 + 32 * c + j], acc[c]);
+                F16 nxt = cur;
+                if (c + 1 < n_ct) nxt = frag_at(Bs, 32 * (c + 1) + j, h);
+                mma_frag(acc[c], a, cur);
+                SCHED_FRAG_STEP();
+                cur = nxt;
             }
         }
         __syncthreads();
@@ -122,10 +152,12 @@ hipError_t launch_gemm_rows(const GemmRows& g, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------
 // part[slice][Mo, No(+1)] = sum over the slice's points of A[p, Mo]^T B[p, No | 1]
+// One workgroup = all Mo (<= 256) rows x 128 columns; the contraction index is the point, so both tiles
+// are transposed while staging: As[m][p], Bs[n][p].
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
-    __shared__ float As[32 * 256];
-    __shared__ float Bs[32 * 128];
+    __shared__ __attribute__((aligned(16))) float As[256 * kLd];
+    __shared__ __attribute__((aligned(16))) float Bs[128 * kLd];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
     const int slice = blockIdx.x;
     const int n0 = blockIdx.y * 128;
@@ -145,6 +177,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
 
     float ra[32], rb[16];
+    const int bn = tid & 127, bp0 = (tid >> 7) * 16;   // B staging: thread = (column, half of the 32 points)
     auto load_tile = [&](int64_t p0) {
 #pragma unroll
         for (int it = 0; it < 32; ++it) {
@@ -153,9 +186,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
         }
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
-            const int e = it * 256 + tid, pr = e >> 7, c = e & 127;
-            const int64_t p = p0 + pr;
-            const int n = n0 + c;
+            const int64_t p = p0 + bp0 + it;
+            const int n = n0 + bn;
             float v = 0.0f;
             if (p < p_end) {
                 if (n < g.No) v = g.B[p * g.ldb + n];
@@ -166,11 +198,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int it = 0; it < 32; ++it) As[it * 256 + tid] = ra[it];
+        for (int q = 0; q < 8; ++q) {
+            f32x4 v = {ra[4 * q], ra[4 * q + 1], ra[4 * q + 2], ra[4 * q + 3]};
+            *(f32x4*)&As[tid * kLd + 4 * q] = v;
+        }
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int e = it * 256 + tid;
-            Bs[(e >> 7) * 128 + (e & 127)] = rb[it];
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = {rb[4 * q], rb[4 * q + 1], rb[4 * q + 2], rb[4 * q + 3]};
+            *(f32x4*)&Bs[bn * kLd + bp0 + 4 * q] = v;
         }
     };
 
@@ -182,16 +217,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
     for (int64_t p0 = p_begin; p0 < p_end; p0 += 32) {
         const bool more = p0 + 32 < p_end;
         if (more) load_tile(p0 + 32);
+        const F16 a0 = frag_at(As, 32 * mt0 + j, h), a1 = frag_at(As, 32 * mt1 + j, h);
+        F16 cur = frag_at(Bs, j, h);
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int pr = 16 * h + t;   // contraction index (the point) of this lane half for k-step t
-            const float a0 = As[pr * 256 + 32 * mt0 + j], a1 = As[pr * 256 + 32 * mt1 + j];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float b = Bs[pr * 128 + 32 * c + j];
-                acc[0][c] = mfma32(a0, b, acc[0][c]);
-                acc[1][c] = mfma32(a1, b, acc[1][c]);
-            }
+        for (int c = 0; c < 4; ++c) {
+            F16 nxt = cur;
+            if (c + 1 < 4) nxt = frag_at(Bs, 32 * (c + 1) + j, h);
+            mma_frag(acc[0][c], a0, cur);
+            SCHED_FRAG_STEP();
+            mma_frag(acc[1][c], a1, cur);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            cur = nxt;
         }
         __syncthreads();
         if (more) {
