@@ -20,6 +20,9 @@ FLAGS = [
     "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
     "-ffp-contract=off",          # PyTorch's op boundaries are rounding boundaries; fmaf is explicit where wanted
     "-fno-fast-math", "-Wall", "-Wno-unused-function",
+    # keep MFMA results in arch VGPRs where the allocator can: the per-layer ReLU then needs no
+    # v_accvgpr_read per element (578 -> 163 in the MLP kernel, +1.1 % frame rate, measured A/B)
+    "-mllvm", "-amdgpu-mfma-vgpr-form",
     "-x", "hip",
 ]
 
