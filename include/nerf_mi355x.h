@@ -200,6 +200,29 @@ typedef struct nerf_camera {
 int nerf_generate_rays(nerf_ctx* ctx, const nerf_camera* cam, int64_t first_pixel, int64_t n_pixels,
                        float* rays /*[dev] [n_pixels, 8|11]*/, void* stream);
 
+/* render() for one camera (nerf.ipynb:558-640) in a single call: ray generation for the flat pixel range
+ * [first_pixel, first_pixel + n_pixels), the batchify_rays chunk loop and render_rays per chunk, all enqueued
+ * on `stream` with no host synchronisation. Deterministic rendering only (perturb = 0, raw_noise_std = 0:
+ * render_kwargs_test); outputs are [n_pixels, ...] in pixel order, optional ones may be NULL. */
+typedef struct nerf_frame_args {
+    nerf_camera cam;
+    int64_t first_pixel, n_pixels;
+    int64_t chunk;              /* rays per render_rays call; <= 0 means 32768 (the reference default)   */
+    int32_t N_samples, N_importance;
+    int32_t slot_coarse, slot_fine;
+    int32_t lindisp, white_bkgd;
+    float* rgb_map;             /* [dev] [n_pixels,3] */
+    float* disp_map;            /* [dev] [n_pixels]   */
+    float* acc_map;             /* [dev] [n_pixels]   */
+    float* rgb0;                /* [dev] optional, N_importance > 0 */
+    float* disp0;
+    float* acc0;
+    float* z_std;
+    void* stream;
+} nerf_frame_args;
+
+int nerf_render_frame(nerf_ctx* ctx, const nerf_frame_args* args);
+
 /* Image metrics -----------------------------------------------------
  * calculate_ssim (nerf/nerf_helpers.py:21-111): separable 11-tap Gaussian (sigma 1.5), zero padded,
  * on [H,W,3] images clamped to [0,max_val]; img2mse (nerf_helpers.py:8). Results are written to

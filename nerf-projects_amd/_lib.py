@@ -17,7 +17,7 @@ EXPORTS = (
     "nerf_load_weights", "nerf_num_weight_tensors", "nerf_embed", "nerf_mlp_forward", "nerf_run_network",
     "nerf_raw2outputs", "nerf_sample_pdf", "nerf_render_rays", "nerf_profile_enable", "nerf_profile_read",
     "nerf_workspace_bytes", "nerf_generate_rays", "nerf_image_metrics", "nerf_train_step", "nerf_get_weights",
-    "nerf_get_gradients", "nerf_stratified_z", "nerf_resample",
+    "nerf_get_gradients", "nerf_stratified_z", "nerf_resample", "nerf_render_frame",
 )
 
 
@@ -55,6 +55,14 @@ class Camera(C.Structure):
                 ("cy", C.c_float), ("c2w", C.c_float * 12), ("c2w_static", C.c_float * 12),
                 ("has_static", C.c_int32), ("ndc", C.c_int32), ("ndc_focal", C.c_double), ("near", C.c_float),
                 ("far", C.c_float), ("use_viewdirs", C.c_int32)]
+
+
+class FrameArgs(C.Structure):
+    _fields_ = [("cam", Camera), ("first_pixel", C.c_int64), ("n_pixels", C.c_int64), ("chunk", C.c_int64),
+                ("N_samples", C.c_int32), ("N_importance", C.c_int32), ("slot_coarse", C.c_int32),
+                ("slot_fine", C.c_int32), ("lindisp", C.c_int32), ("white_bkgd", C.c_int32), ("rgb_map", _FP),
+                ("disp_map", _FP), ("acc_map", _FP), ("rgb0", _FP), ("disp0", _FP), ("acc0", _FP), ("z_std", _FP),
+                ("stream", C.c_void_p)]
 
 
 _lib = None
@@ -119,6 +127,8 @@ def load():
     lib.nerf_stratified_z.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp, vp]
     lib.nerf_resample.restype = i32
     lib.nerf_resample.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp]
+    lib.nerf_render_frame.restype = i32
+    lib.nerf_render_frame.argtypes = [vp, C.POINTER(FrameArgs)]
     lib.nerf_workspace_bytes.restype = i64
     lib.nerf_workspace_bytes.argtypes = [vp]
     _lib = lib

@@ -166,6 +166,7 @@ void nerf_ctx_destroy(nerf_ctx* c) {
     (void)hipDeviceSynchronize();
     for (auto& n : c->nets) free_net(n);
     if (c->ws) (void)hipFree(c->ws);
+    if (c->frame_rays) (void)hipFree(c->frame_rays);
     for (auto& p : c->events) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -483,6 +484,61 @@ int nerf_generate_rays(nerf_ctx* c, const nerf_camera* cam, int64_t first_pixel,
     }
     DeviceGuard g(c->device);
     HIP_TRY(launch_raygen(*cam, first_pixel, n_pixels, rays, (hipStream_t)stream));
+    return NERF_OK;
+}
+
+int nerf_render_frame(nerf_ctx* c, const nerf_frame_args* f) {
+    if (!c || !f || f->first_pixel < 0 || f->n_pixels < 0) {
+        set_error("nerf_render_frame: invalid argument");
+        return NERF_E_INVALID;
+    }
+    if (f->cam.H <= 0 || f->cam.W <= 0 || f->first_pixel + f->n_pixels > (int64_t)f->cam.H * f->cam.W) {
+        set_error("nerf_render_frame: pixels [%lld, %lld) outside the %dx%d image", (long long)f->first_pixel,
+                  (long long)(f->first_pixel + f->n_pixels), f->cam.H, f->cam.W);
+        return NERF_E_INVALID;
+    }
+    if (f->n_pixels == 0) return NERF_OK;
+    const int64_t chunk = f->chunk > 0 ? f->chunk : 32768;
+    const int ld = f->cam.use_viewdirs ? 11 : 8;
+    const int64_t per = chunk < f->n_pixels ? chunk : f->n_pixels;
+    DeviceGuard g(c->device);
+    hipStream_t s = (hipStream_t)f->stream;
+    if ((size_t)per * ld > c->frame_rays_floats) {
+        if (c->frame_rays) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(c->frame_rays));
+            c->frame_rays = nullptr;
+            c->frame_rays_floats = 0;
+        }
+        HIP_TRY(hipMalloc((void**)&c->frame_rays, (size_t)per * ld * sizeof(float)));
+        c->frame_rays_floats = (size_t)per * ld;
+    }
+    for (int64_t off = 0; off < f->n_pixels; off += chunk) {
+        const int64_t n = off + chunk <= f->n_pixels ? chunk : f->n_pixels - off;
+        // stream order makes reusing the one ray buffer safe: chunk k+1's generation runs after chunk k's kernels
+        HIP_TRY(launch_raygen(f->cam, f->first_pixel + off, n, c->frame_rays, s));
+        nerf_render_args r;
+        memset(&r, 0, sizeof(r));
+        r.rays = c->frame_rays;
+        r.n_rays = n;
+        r.ray_stride = ld;
+        r.N_samples = f->N_samples;
+        r.N_importance = f->N_importance;
+        r.slot_coarse = f->slot_coarse;
+        r.slot_fine = f->slot_fine;
+        r.lindisp = f->lindisp;
+        r.white_bkgd = f->white_bkgd;
+        r.rgb_map = f->rgb_map ? f->rgb_map + off * 3 : nullptr;
+        r.disp_map = f->disp_map ? f->disp_map + off : nullptr;
+        r.acc_map = f->acc_map ? f->acc_map + off : nullptr;
+        r.rgb0 = f->rgb0 ? f->rgb0 + off * 3 : nullptr;
+        r.disp0 = f->disp0 ? f->disp0 + off : nullptr;
+        r.acc0 = f->acc0 ? f->acc0 + off : nullptr;
+        r.z_std = f->z_std ? f->z_std + off : nullptr;
+        r.stream = f->stream;
+        const int rc = nerf_render_rays(c, &r);
+        if (rc != NERF_OK) return rc;
+    }
     return NERF_OK;
 }
 

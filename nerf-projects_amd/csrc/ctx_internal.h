@@ -21,6 +21,8 @@ struct nerf_ctx {
     nerf::PackedNet nets[NERF_NUM_SLOTS];
     char* ws = nullptr;          // workspace arena
     size_t ws_bytes = 0;
+    float* frame_rays = nullptr;   // ray record of the chunk being rendered by nerf_render_frame
+    size_t frame_rays_floats = 0;
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per MLP launch
     std::vector<hipEvent_t> pool;

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Camera, NerfArch, RenderArgs, TrainArgs, check
+from ._lib import Camera, FrameArgs, NerfArch, RenderArgs, TrainArgs, check
 
 __all__ = [
     "NeRF", "get_embedder", "batchify", "run_network", "raw2outputs", "sample_pdf", "render_rays",
@@ -671,13 +671,7 @@ def _mat34(m):
     return np.ascontiguousarray(m[:3, :4]).reshape(-1)
 
 
-def generate_rays(H, W, K, c2w, ndc=True, near=0., far=1., use_viewdirs=False, c2w_staticcam=None,
-                  first_pixel=0, n_pixels=None, device=None):
-    """The ``[n_pixels, 8|11]`` ray record of ``render()`` (nerf.ipynb:596-629) generated on the GPU by
-    one kernel (``get_rays`` + viewdir normalisation + optional ``ndc_rays`` + near/far columns) for the
-    flat pixel range ``[first_pixel, first_pixel + n_pixels)``: no host ray generation, no 28 MB H2D copy,
-    and a rank of a sharded render only ever materialises its own shard."""
-    ctx = get_context(device)
+def _camera(H, W, K, c2w, ndc, near, far, use_viewdirs, c2w_staticcam):
     cam = Camera()
     cam.H, cam.W = int(H), int(W)
     # torch computes (i - K[0][2]) / K[0][0] in fp32 with the Python/numpy scalars cast to fp32
@@ -688,11 +682,54 @@ def generate_rays(H, W, K, c2w, ndc=True, near=0., far=1., use_viewdirs=False, c
         cam.has_static = 1
     cam.ndc, cam.ndc_focal = int(bool(ndc)), float(K[0][0])
     cam.near, cam.far, cam.use_viewdirs = float(near), float(far), int(bool(use_viewdirs))
-    total = cam.H * cam.W
-    n = total - first_pixel if n_pixels is None else int(n_pixels)
+    return cam
+
+
+def generate_rays(H, W, K, c2w, ndc=True, near=0., far=1., use_viewdirs=False, c2w_staticcam=None,
+                  first_pixel=0, n_pixels=None, device=None):
+    """The ``[n_pixels, 8|11]`` ray record of ``render()`` (nerf.ipynb:596-629) generated on the GPU by
+    one kernel (``get_rays`` + viewdir normalisation + optional ``ndc_rays`` + near/far columns) for the
+    flat pixel range ``[first_pixel, first_pixel + n_pixels)``: no host ray generation, no 28 MB H2D copy,
+    and a rank of a sharded render only ever materialises its own shard."""
+    ctx = get_context(device)
+    cam = _camera(H, W, K, c2w, ndc, near, far, use_viewdirs, c2w_staticcam)
+    n = cam.H * cam.W - first_pixel if n_pixels is None else int(n_pixels)
     out = torch.empty((n, 11 if use_viewdirs else 8), device=ctx.device, dtype=torch.float32)
     check(ctx.lib.nerf_generate_rays(ctx.handle, C.byref(cam), int(first_pixel), n, _ptr(out), ctx.stream()))
     return out
+
+
+def _render_frame_fused(ctx, cam, first_pixel, n_pixels, chunk, net_c, net_f, N_samples, N_importance, lindisp,
+                        white_bkgd):
+    """One ``nerf_render_frame`` call: ray generation + chunk loop + render_rays, nothing but kernels enqueued."""
+    o = dict(device=ctx.device, dtype=torch.float32)
+    ret = {"rgb_map": torch.empty((n_pixels, 3), **o), "disp_map": torch.empty((n_pixels,), **o),
+           "acc_map": torch.empty((n_pixels,), **o)}
+    f = FrameArgs()
+    f.cam, f.first_pixel, f.n_pixels, f.chunk = cam, int(first_pixel), int(n_pixels), int(chunk)
+    f.N_samples, f.N_importance = int(N_samples), int(N_importance)
+    f.slot_coarse, f.slot_fine = net_c.slot, (net_f.slot if net_f is not None else -1)
+    f.lindisp, f.white_bkgd = int(bool(lindisp)), int(bool(white_bkgd))
+    f.rgb_map, f.disp_map, f.acc_map = (ret[k].data_ptr() for k in ("rgb_map", "disp_map", "acc_map"))
+    if N_importance > 0:
+        ret.update(rgb0=torch.empty((n_pixels, 3), **o), disp0=torch.empty((n_pixels,), **o),
+                   acc0=torch.empty((n_pixels,), **o), z_std=torch.empty((n_pixels,), **o))
+        f.rgb0, f.disp0, f.acc0, f.z_std = (ret[k].data_ptr() for k in ("rgb0", "disp0", "acc0", "z_std"))
+    f.stream = ctx.stream().value
+    check(ctx.lib.nerf_render_frame(ctx.handle, C.byref(f)))
+    return ret
+
+
+def _frame_call_applies(kwargs):
+    """render() can hand the whole frame to one C call when nothing random or opaque is involved."""
+    q, net, fine = kwargs.get('network_query_fn'), kwargs.get('network_fn'), kwargs.get('network_fine')
+    try:
+        noise = float(kwargs.get('raw_noise_std', 0.))
+    except (TypeError, ValueError):
+        noise = 0.0
+    return (isinstance(q, NetworkQuery) and isinstance(net, NeRF) and (fine is None or isinstance(fine, NeRF))
+            and float(kwargs.get('perturb', 0.)) == 0. and noise == 0. and not kwargs.get('retraw', False)
+            and not kwargs.get('pytest', False))
 
 
 def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
@@ -701,6 +738,17 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     With ``c2w`` the rays are generated on the GPU (:func:`generate_rays`); a ``rays`` tuple is
     packed with torch ops exactly as the reference does."""
     model_device = next(kwargs['network_fn'].parameters()).device
+    if c2w is not None and _frame_call_applies(kwargs) and \
+            kwargs['network_query_fn'].matches(kwargs['network_fn'], bool(use_viewdirs)):
+        net = kwargs['network_fn']
+        cam = _camera(H, W, K, c2w, ndc, near, far, use_viewdirs, c2w_staticcam)
+        all_ret = _render_frame_fused(net.ctx, cam, 0, int(H) * int(W), chunk, net, kwargs.get('network_fine'),
+                                      kwargs['N_samples'], kwargs.get('N_importance', 0),
+                                      kwargs.get('lindisp', False), kwargs.get('white_bkgd', False))
+        for k in all_ret:
+            all_ret[k] = torch.reshape(all_ret[k], [H, W] + list(all_ret[k].shape[1:]))
+        k_extract = ['rgb_map', 'disp_map', 'acc_map']
+        return [all_ret[k] for k in k_extract] + [{k: all_ret[k] for k in all_ret if k not in k_extract}]
     if c2w is not None:
         packed = generate_rays(H, W, K, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, device=model_device)
         sh = (H, W, 3)

@@ -78,10 +78,18 @@ def render_sharded(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near
     device = None
     if 'network_fn' in kwargs and hasattr(kwargs['network_fn'], 'parameters'):
         device = next(kwargs['network_fn'].parameters()).device
-    packed, sh = host.pack_rays(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, device=device)
-    n_total = packed.shape[0]
-    lo, hi = shard_bounds(n_total, world, rank)
-    ret = render_chunks(packed[lo:hi], chunk, **kwargs)
+    if c2w is not None and isinstance(kwargs.get('network_fn'), host.NeRF):
+        # each rank generates only its own shard of the frame's rays, on its GPU
+        n_total, sh = int(H) * int(W), (H, W, 3)
+        lo, hi = shard_bounds(n_total, world, rank)
+        shard = host.generate_rays(H, W, K, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, first_pixel=lo,
+                                   n_pixels=hi - lo, device=device)
+    else:
+        packed, sh = host.pack_rays(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, device=device)
+        n_total = packed.shape[0]
+        lo, hi = shard_bounds(n_total, world, rank)
+        shard = packed[lo:hi]
+    ret = render_chunks(shard, chunk, **kwargs)
     local = {k: ret[k] for k in keys}
     if world == 1:
         full = local

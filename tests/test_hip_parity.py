@@ -626,3 +626,23 @@ def test_load_weights_from_keras(N):
     g = load_golden("mlp_forward")
     out = cpu(net(gpu(g["embedded"])))
     assert np.abs(out - g["out"]).max() <= 3e-6 * max(1.0, np.abs(g["out"]).max())
+
+
+def test_frame_call_equals_chunk_loop(N, nets):
+    """render() through the single nerf_render_frame call == generate_rays + batchify_rays, bit for bit,
+    and render_sharded (one rank) returns the same frame."""
+    net_c, net_f, q = nets
+    K, c2w, near, far = synthetic.lego_camera(40, 56)
+    kw = dict(network_fn=net_c, network_fine=net_f, network_query_fn=q, N_samples=24, N_importance=24, white_bkgd=True)
+    rgb, disp, acc, extras = N.render(40, 56, K, chunk=300, c2w=c2w, ndc=False, near=near, far=far,
+                                      use_viewdirs=True, **kw)
+    rays = N.generate_rays(40, 56, K, c2w, ndc=False, near=near, far=far, use_viewdirs=True)
+    ref = N.batchify_rays(rays, 300, **kw)
+    assert torch.equal(rgb.reshape(-1, 3), ref["rgb_map"]) and torch.equal(disp.reshape(-1), ref["disp_map"])
+    assert torch.equal(extras["rgb0"].reshape(-1, 3), ref["rgb0"]) and torch.equal(extras["z_std"].reshape(-1), ref["z_std"])
+    out = N.render_sharded(40, 56, K, chunk=300, c2w=c2w, ndc=False, near=near, far=far, use_viewdirs=True, **kw)
+    assert torch.equal(out[0], rgb) and torch.equal(out[2], acc)
+    # training kwargs (perturb / noise) keep using the per-chunk route with the package's RNG
+    rgb_t = N.render(40, 56, K, chunk=300, c2w=c2w, ndc=False, near=near, far=far, use_viewdirs=True,
+                     perturb=1.0, raw_noise_std=1.0, **kw)[0]
+    assert torch.isfinite(rgb_t).all() and not torch.equal(rgb_t, rgb)
