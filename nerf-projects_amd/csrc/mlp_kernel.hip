@@ -28,9 +28,10 @@
 //   * Biases are pre-arranged per accumulator register and read from LDS straight into
 //     the accumulator tile (no MFMA, no VALU).
 //
-// Roofline: 593,408 MAC/point -> 9,464 MFMA per 32 points (98.0 % of them useful; the
-// rest is K/N padding of the 63-, 27-, 1- and 3-wide edges). Bound: fp32 MFMA,
-// 64 cycles per v_mfma_f32_32x32x2_f32 per SIMD, 157.3 TFLOP/s per chip.
+// Roofline: 593,408 MAC/point -> 9,280 MFMA per 32 points (99.8 % of them useful; the rest
+// is K padding of the 63- and 27-wide encodings; the 1-row alpha and 3-row rgb heads are VALU
+// dot products). Bound: fp32 MFMA, 64 cycles per v_mfma_f32_32x32x2_f32 per SIMD,
+// 157.3 TFLOP/s per chip.
 #include "nerf_internal.h"
 
 namespace nerf {
@@ -204,6 +205,25 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[8], const float* bias_ld
         acc[ot] = *(const f32x16*)(bias_lds + ((tile + ot) * 2 + h) * 16);
 }
 
+// One output row of a Linear over NKT activation tiles held in registers: this lane's 16*NKT products
+// (weights arranged per register in the bias block, see pack_weights.cpp row_tiles) plus the other
+// half-wave's. Both half-waves return the full sum.
+template <int NKT>
+__device__ __forceinline__ float row_dot(const f32x16 (&x)[8], const float* bias_lds, int tile, int h) {
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const f32x16 w = *(const f32x16*)(bias_lds + ((tile + kt) * 2 + h) * 16);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            s0 = fmaf(w[r], x[kt][r], s0);
+            s1 = fmaf(w[r + 1], x[kt][r + 1], s1);
+        }
+    }
+    const float s = s0 + s1;
+    return s + __shfl_xor(s, 32);
+}
+
 template <int N, bool RELU>
 __device__ __forceinline__ void activate(f32x16 (&dst)[8], const f32x16 (&src)[8]) {
 #pragma unroll
@@ -352,10 +372,9 @@ void nerf_mlp_kernel(const MlpLaunch a) {
     for (int i = 1; i < n_layers; ++i) {
         const bool is_feature = (i == a.D);
         if (is_feature) {
-            // alpha_linear reads the post-ReLU trunk output before feature_linear (nerf.py:86-89)
-            f32x16 al = *(const f32x16*)(bias_lds + ((8 * a.D) * 2 + h) * 16);
-            chunk_row<8>(pipe, cur, al, hid);
-            sigma = al[0];   // row 0 lives in register 0 of half-wave 0
+            // alpha_linear reads the post-ReLU trunk output before feature_linear (nerf.py:86-89): one output
+            // row, evaluated as a dot product over the 128 activations this lane holds + the other half-wave's
+            sigma = row_dot<8>(hid, bias_lds, 8 * a.D + 14, h) + bias_lds[(8 * a.D) * 32];
         }
         load_bias<8>(acc, bias_lds, is_feature ? 8 * a.D + 1 : 8 * i, h);
         if (!is_feature && ((a.skip_in_mask >> i) & 1)) {
@@ -376,12 +395,14 @@ void nerf_mlp_kernel(const MlpLaunch a) {
         for (int kp = 0; kp < 4; ++kp) chunk_pair4(pipe, cur, acc, hid[2 * kp], hid[2 * kp + 1]);
         chunk_ktile4(pipe, cur, acc, dd);
         activate<4, true>(hid, acc);
-        // rgb_linear (nerf.py:101)
-        f32x16 rgb = *(const f32x16*)(bias_lds + ((8 * a.D + 13) * 2 + h) * 16);
-        chunk_row<4>(pipe, cur, rgb, hid);
+        // rgb_linear (nerf.py:101): three output rows over the 128-wide view layer, as dot products
+        const float* rb = bias_lds + (8 * a.D + 13) * 32;
+        const float r0 = row_dot<4>(hid, bias_lds, 8 * a.D + 22, h) + rb[0];
+        const float r1 = row_dot<4>(hid, bias_lds, 8 * a.D + 26, h) + rb[1];
+        const float r2 = row_dot<4>(hid, bias_lds, 8 * a.D + 30, h) + rb[2];
         if (live && h == 0) {
             // outputs = cat[rgb, alpha] (nerf.py:106)
-            f32x4 o = {rgb[0], rgb[1], rgb[2], sigma};
+            f32x4 o = {r0, r1, r2, sigma};
             *(f32x4*)(a.out + pt * 4) = o;
         }
     } else {

@@ -18,7 +18,7 @@ constexpr int kChunkFloats = 8192;
 constexpr int kChunkBytes = kChunkFloats * 4;
 constexpr int kGroupFloats = 256;            // 64 lanes x 4 k-steps
 constexpr int kBiasTileFloats = 32;          // [h(2)][16 accumulator registers]
-constexpr int kBiasLdsBytes = 16384;         // up to 128 bias tiles
+constexpr int kBiasLdsBytes = 20480;         // up to 160 bias / row-vector tiles
 constexpr int kWidth = 256;                  // trunk width this build is specialised for
 constexpr int kMaxDepth = 12;
 constexpr int kPointsPerWave = 32;

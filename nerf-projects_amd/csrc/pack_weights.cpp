@@ -82,6 +82,14 @@ void bias_tiles(std::vector<float>& out, const Linear& L, int n_ot) {
             for (int r = 0; r < 16; ++r) out.push_back(L.bias(32 * ot + (r & 3) + 8 * (r >> 2) + 4 * h));
 }
 
+// row `row` of a weight matrix over its first 32*n_kt input columns, in accumulator-register order:
+// tile kt, half h, register r holds W[row][32*kt + (r&3) + 8*(r>>2) + 4*h]
+void row_tiles(std::vector<float>& out, const Linear& L, int row, int n_kt) {
+    for (int kt = 0; kt < n_kt; ++kt)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) out.push_back(L.at(row, hidden_col(kt, r, h)));
+}
+
 }  // namespace
 
 int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors, float** stream_out,
@@ -173,14 +181,11 @@ int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors,
         Linear feature{head[0], head[1], a.W, a.W};
         Linear alpha{head[2], head[3], 1, a.W};
         Linear rgb{head[4], head[5], 3, a.W / 2};
-        // alpha_linear (nerf.py:86): one output tile over all 8 k-tiles: group = kt*4 + t4
-        {
-            float* c = st.new_chunk();
-            for (int kt = 0; kt < 8; ++kt)
-                for (int t4 = 0; t4 < 4; ++t4)
-                    fill_group(c, kt * 4 + t4, alpha, 0, t4, [kt](int t, int h) { return hidden_col(kt, t, h); });
-            bias_tiles(bias, alpha, 1);
-        }
+        // alpha_linear (nerf.py:86) and rgb_linear (nerf.py:101) have 1 and 3 output rows: as MFMA tiles they
+        // would be 97 % / 91 % padding (128 + 64 MFMAs per 32 points), so the kernel evaluates them as
+        // per-lane dot products over the activation registers it already holds. Their weights travel in the
+        // bias block, arranged per accumulator register exactly like a bias (row_tiles below).
+        bias_tiles(bias, alpha, 1);
         // feature_linear (nerf.py:89): a trunk-shaped layer without ReLU
         bias_tiles(bias, feature, 8);
         for (int kt = 0; kt < 8; ++kt)
@@ -206,14 +211,9 @@ int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors,
                 return (c >= 0 && c < nv) ? off + c : -1;
             });
         }
-        // rgb_linear (nerf.py:101): one output tile over the 4 k-tiles of the 128-wide view layer
-        {
-            float* c = st.new_chunk();
-            for (int kt = 0; kt < 4; ++kt)
-                for (int t4 = 0; t4 < 4; ++t4)
-                    fill_group(c, kt * 4 + t4, rgb, 0, t4, [kt](int t, int h) { return hidden_col(kt, t, h); });
-            bias_tiles(bias, rgb, 1);
-        }
+        bias_tiles(bias, rgb, 1);
+        row_tiles(bias, alpha, 0, 8);                       // tiles 8D+14 .. 8D+21
+        for (int c = 0; c < 3; ++c) row_tiles(bias, rgb, c, 4);   // tiles 8D+22+4c ..
         *out_ch = 4;   // cat[rgb, alpha] (nerf.py:106)
     } else {
         Linear outl{head[0], head[1], a.output_ch, a.W};
