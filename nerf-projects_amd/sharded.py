@@ -30,7 +30,7 @@ def gather_frame(local, n_total, group=None, dst=0, force_collective=False):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     names = sorted(local)
-    widths = [int(local[k][0].numel()) if local[k].dim() > 1 else 1 for k in names]
+    widths = [int(torch.Size(local[k].shape[1:]).numel()) for k in names]      # 1 for [n] fields; works for empty shards
     shapes = [tuple(local[k].shape[1:]) for k in names]
     n_local = local[names[0]].shape[0]
     n_max = -(-n_total // world)

@@ -65,6 +65,20 @@ def _worker(rank, world, port, H, W, q):
         dist.destroy_process_group()
 
 
+def test_gather_frame_single_process_with_empty_fields():
+    import nerf_projects_amd as N
+    local = {"rgb_map": torch.arange(12, dtype=torch.float32).reshape(4, 3), "acc_map": torch.arange(4.)}
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        out = N.gather_frame(local, 4, force_collective=True)
+        assert torch.equal(out["rgb_map"], local["rgb_map"]) and torch.equal(out["acc_map"], local["acc_map"])
+        empty = {"rgb_map": torch.zeros(0, 3), "acc_map": torch.zeros(0)}
+        out = N.gather_frame(empty, 0)
+        assert out["rgb_map"].shape == (0, 3) and out["acc_map"].shape == (0,)
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("H,W", [(6, 8), (5, 7)])          # even and uneven (35 rays over 2 ranks)
 def test_two_rank_gloo_render(H, W):
     ctx = mp.get_context("spawn")
