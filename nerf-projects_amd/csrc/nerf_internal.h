@@ -121,13 +121,13 @@ struct GemmRows {      // C[M,N] = A[M,K] B[K,N]  (+bias) (ReLU) (C *= mask > 0)
     const float* mask; int ldm;
     int accumulate;
 };
-struct GemmTN {        // part[slice][Mo, No(+1)] = sum_p A[p,Mo]^T [B[p,No] | 1]
+struct GemmTN {        // part[slice][Mo, No] = sum_p A[p,Mo]^T B[p,No];  dbp[slice][Mo] = sum_p A[p,Mo]
     const float* A; int lda;
     const float* B; int ldb;
     int64_t P; int Mo, No;
-    int ones;
     int64_t pts_per_slice;
     float* part;
+    float* dbp;
 };
 hipError_t launch_gemm_rows(const GemmRows& g, hipStream_t s);
 hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, float* db, hipStream_t s);

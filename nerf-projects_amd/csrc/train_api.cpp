@@ -148,16 +148,31 @@ int forward_pass(Pass& ps, const float* rays, int ray_ld, const float* z, hipStr
 }
 
 struct TnScratch {
-    float* part;
-    int n_slices;
-    int64_t pts_per_slice;
+    float* part;      // [max_slices][256][No <= 320] partial dW
+    float* dbp;       // [max_slices][256] partial db
+    int max_slices;
+    int64_t P;        // points of the pass being differentiated
 };
+
+// Slices per GEMM: the grid is slices x ceil(No/128) workgroups at one per CU, so aim at a whole number of
+// 256-workgroup rounds (a 1.5-round grid wastes a third of the machine) while keeping >= 256 points per slice.
+inline int pick_slices(int64_t P, int No, int max_slices) {
+    const int yb = (No + 127) / 128;
+    int s = 256 / yb;
+    const int64_t cap = (P + 255) / 256;
+    if (s > cap) s = (int)cap;
+    if (s > max_slices) s = max_slices;
+    return s < 1 ? 1 : s;
+}
 
 // dW (+db) of one Linear: dW = dY^T X, db = dY^T 1
 int grad_linear(const PackedNet& net, const LinearDesc& d, const float* dY, int ldy, const float* X, int ldx, int64_t P,
                 const TnScratch& sc, hipStream_t s) {
-    GemmTN g{dY, ldy, X, ldx, P, d.out, d.in, 1, sc.pts_per_slice, sc.part};
-    HIP_TRY(launch_gemm_tn(g, sc.n_slices, net.train.d_grad + d.w_off, d.in, net.train.d_grad + d.b_off, s));
+    const int n_slices = pick_slices(P, d.in, sc.max_slices);
+    int64_t pps = (P + n_slices - 1) / n_slices;
+    pps = (pps + 31) / 32 * 32;
+    GemmTN g{dY, ldy, X, ldx, P, d.out, d.in, pps, sc.part, sc.dbp};
+    HIP_TRY(launch_gemm_tn(g, n_slices, net.train.d_grad + d.w_off, d.in, net.train.d_grad + d.b_off, s));
     return NERF_OK;
 }
 
@@ -278,12 +293,11 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
 
     // workspace: sampling buffers + both passes + split-K partials
     const int64_t Pc = N * Sc, Pf = Si ? N * Sf : 0;
-    int n_slices = (int)((((Pf > Pc ? Pf : Pc) + 1023) / 1024));
-    if (n_slices > 256) n_slices = 256;
-    if (n_slices < 1) n_slices = 1;
+    const int n_slices = 256;
     const size_t part_floats = (size_t)n_slices * 256 * (size_t)(nc.arch.W + nc.arch.input_ch + 64);
     const size_t small = (size_t)N * (Sc * 2 + (Si ? Si + Sf * 2 : 0) + 16) + 4096;
-    rc = ensure_workspace(c, arena_bytes({small, pass_floats(nc, Pc), Si ? pass_floats(nf, Pf) : 1, part_floats}) +
+    rc = ensure_workspace(c, arena_bytes({small, pass_floats(nc, Pc), Si ? pass_floats(nf, Pf) : 1, part_floats,
+                                          (size_t)n_slices * 256}) +
                                  (1 << 20));
     if (rc != NERF_OK) return rc;
     Arena ar(c->ws);
@@ -298,7 +312,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     float* g_f = Si ? ar.take((size_t)N * 3) : nullptr;
     double* red = (double*)ar.take(2048);   // 2 x 512 doubles of per-block partials
     float* loss_dev = ar.take(4);
-    TnScratch sc{ar.take(part_floats), n_slices, 0};
+    TnScratch sc{ar.take(part_floats), ar.take((size_t)n_slices * 256), n_slices, 0};
 
     Pass pc;
     pc.net = &nc;
@@ -314,11 +328,6 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
         pf.S = Sf;
         carve_pass(ar, pf);
     }
-    auto slices_for = [&](int64_t P) {
-        int64_t pps = (P + n_slices - 1) / n_slices;
-        pps = (pps + 31) / 32 * 32;
-        return pps;
-    };
 
     // ---- forward (render(..., retraw=True, **render_kwargs_train), nerf.ipynb:1258) ----
     HIP_TRY(launch_stratified(r->rays, r->ray_stride, N, Sc, r->lindisp, r->perturb ? r->t_rand : nullptr, z_c, s));
@@ -345,13 +354,13 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     // ---- backward ----
     HIP_TRY(launch_composite_bwd(pc.raw, pc.C, z_c, r->rays + 3, r->ray_stride, r->noise0, r->white_bkgd, N, Sc, g_c,
                                  pc.d_raw, s));
-    sc.pts_per_slice = slices_for(Pc);
+    sc.P = Pc;
     if ((rc = backward_pass(pc, sc, s))) return rc;
     nc.train.grads_valid = true;
     if (Si) {
         HIP_TRY(launch_composite_bwd(pf.raw, pf.C, z_f, r->rays + 3, r->ray_stride, r->noise, r->white_bkgd, N, Sf, g_f,
                                      pf.d_raw, s));
-        sc.pts_per_slice = slices_for(Pf);
+        sc.P = Pf;
         if ((rc = backward_pass(pf, sc, s))) return rc;
         nf.train.grads_valid = true;
     }

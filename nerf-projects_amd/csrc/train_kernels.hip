@@ -56,185 +56,237 @@ __device__ __forceinline__ void mma_frag(f32x16& acc, const F16& a, const F16& b
 
 // ---------------------------------------------------------------------------------------------
 // C[M,N] = A[M,K] * B[K,N]      (N <= 256, any K; one workgroup = 128 rows x all N columns)
+//
+// Eight waves per workgroup with fixed roles (two per SIMD): waves 0-3 are MFMA consumers (32 rows x 256
+// columns each, 128 accumulator registers), waves 4-7 are loaders that stage the NEXT k-tile (global ->
+// registers -> LDS, transposing B so that both tiles are K-contiguous) into the other half of a double
+// buffer while the consumers run the 128 MFMAs of the current one. One barrier per k-tile. The loaders'
+// predicated dword loads and address arithmetic run on the vector/memory pipes beside the consumers'
+// matrix pipe instead of in front of it.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm_rows_kernel(GemmRows g) {
-    __shared__ __attribute__((aligned(16))) float As[128 * kLd];   // [row of A][k]
-    __shared__ __attribute__((aligned(16))) float Bs[256 * kLd];   // [column of B][k]  (transposed while staging)
+__global__ __launch_bounds__(512) void gemm_rows_kernel(GemmRows g) {
+    extern __shared__ __attribute__((aligned(16))) float lds_rows[];
+    float* As = lds_rows;                       // [2][128 * kLd]   rows of A, K-contiguous
+    float* Bs = lds_rows + 2 * 128 * kLd;       // [2][256 * kLd]   columns of B, K-contiguous
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
+    const bool consumer = wave < 4;             // wave-uniform
+    const int ptid = tid & 255;
     const int64_t row0 = (int64_t)blockIdx.x * 128;
-    const int n_ct = (g.N + 31) >> 5;   // column tiles in use (<= 8), uniform
+    const int n_ct = (g.N + 31) >> 5;           // column tiles in use (<= 8), uniform
+    const int n_kt = (g.K + 31) >> 5;
 
-    f32x16 acc[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
-
-    // global -> registers (issued one k-tile ahead) -> LDS
-    float ra[16], rb[32];
-    auto load_tile = [&](int k0) {
+    auto stage = [&](int kt, int buf) {         // loaders only
+        const int k0 = kt * 32;
+        float* as = As + buf * 128 * kLd;
+        float* bs = Bs + buf * 256 * kLd;
+        float ra[16], rb[32];
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
-            const int e = it * 256 + tid, r = e >> 5, c = e & 31;
+            const int e = it * 256 + ptid, r = e >> 5, c = e & 31;
             const int64_t gr = row0 + r;
             ra[it] = (gr < g.M && k0 + c < g.K) ? g.A[gr * g.lda + k0 + c] : 0.0f;
         }
 #pragma unroll
         for (int it = 0; it < 32; ++it)
-            rb[it] = (k0 + it < g.K && tid < g.N) ? g.B[(int64_t)(k0 + it) * g.ldb + tid] : 0.0f;
-    };
-    auto store_tile = [&]() {
+            rb[it] = (k0 + it < g.K && ptid < g.N) ? g.B[(int64_t)(k0 + it) * g.ldb + ptid] : 0.0f;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
-            const int e = it * 256 + tid;
-            As[(e >> 5) * kLd + (e & 31)] = ra[it];
+            const int e = it * 256 + ptid;
+            as[(e >> 5) * kLd + (e & 31)] = ra[it];
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {   // thread = column n: its 32 k values, 16 bytes at a time
+        for (int q = 0; q < 8; ++q) {           // thread = column n: its 32 k values, 16 bytes at a time
             f32x4 v = {rb[4 * q], rb[4 * q + 1], rb[4 * q + 2], rb[4 * q + 3]};
-            *(f32x4*)&Bs[tid * kLd + 4 * q] = v;
+            *(f32x4*)&bs[ptid * kLd + 4 * q] = v;
         }
     };
 
-    load_tile(0);
-    store_tile();
-    __syncthreads();
-    for (int k0 = 0; k0 < g.K; k0 += 32) {
-        const bool more = k0 + 32 < g.K;
-        if (more) load_tile(k0 + 32);
-        const F16 a = frag_at(As, 32 * wave + j, h);
-        F16 cur = frag_at(Bs, j, h);
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    f32x16 acc[8];
+    if (consumer) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            if (c < n_ct) {
-                F16 nxt = cur;
-                if (c + 1 < n_ct) nxt = frag_at(Bs, 32 * (c + 1) + j, h);
-                mma_frag(acc[c], a, cur);
-                SCHED_FRAG_STEP();
-                cur = nxt;
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+    } else {
+        stage(0, 0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < n_kt; ++kt) {
+        if (consumer) {
+            const float* as = As + (kt & 1) * 128 * kLd;
+            const float* bs = Bs + (kt & 1) * 256 * kLd;
+            const F16 a = frag_at(as, 32 * wave + j, h);
+            F16 cur = frag_at(bs, j, h);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (c < n_ct) {
+                    F16 nxt = cur;
+                    if (c + 1 < n_ct) nxt = frag_at(bs, 32 * (c + 1) + j, h);
+                    mma_frag(acc[c], a, cur);
+                    SCHED_FRAG_STEP();
+                    cur = nxt;
+                }
             }
+        } else if (kt + 1 < n_kt) {
+            stage(kt + 1, (kt + 1) & 1);
         }
         __syncthreads();
-        if (more) {
-            store_tile();
-            __syncthreads();
-        }
     }
-    // D[row][col]: col = lane & 31 (-> n), row = (reg & 3) + 8*(reg >> 2) + 4*h (-> point)
+    if (!consumer) return;
+    // D[row][col]: col = lane & 31 (-> n), row = (reg & 3) + 8*(reg >> 2) + 4*h (-> point).
+    // The optional reads (old C for accumulate, the ReLU mask) are batched per column tile from clamped
+    // addresses under wave-uniform flags, so 16 loads are in flight at a time instead of one.
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         if (c >= n_ct) continue;
         const int n = 32 * c + j;
-        if (n >= g.N) continue;
-        const float bias = g.bias ? g.bias[n] : 0.0f;
+        const bool n_ok = n < g.N;
+        const int ncl = n_ok ? n : g.N - 1;
+        const float bias = g.bias ? g.bias[ncl] : 0.0f;
+        int64_t rowv[16];
+        float oldv[16], maskv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t row = row0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row >= g.M) continue;
+            rowv[r] = row < g.M ? row : g.M - 1;
+        }
+        if (g.accumulate) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oldv[r] = g.C[rowv[r] * g.ldc + ncl];
+        }
+        if (g.mask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) maskv[r] = g.mask[rowv[r] * g.ldm + ncl];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
             float v = acc[c][r];
-            float* dst = g.C + row * g.ldc + n;
-            if (g.accumulate) v += *dst;
+            if (g.accumulate) v += oldv[r];
             if (g.bias) v += bias;
             if (g.relu) v = fmaxf(v, 0.0f);
-            if (g.mask && !(g.mask[row * g.ldm + n] > 0.0f)) v = 0.0f;   // ReLU'(pre) = [post > 0]
-            *dst = v;
+            if (g.mask && !(maskv[r] > 0.0f)) v = 0.0f;   // ReLU'(pre) = [post > 0]
+            if (n_ok && row < g.M) g.C[row * g.ldc + n] = v;
         }
     }
+}
+
+constexpr size_t kRowsLds = (size_t)(2 * 128 * kLd + 2 * 256 * kLd) * sizeof(float);   // 108 KiB
+constexpr size_t kTnLds = (size_t)(2 * 256 * kLd + 2 * 128 * kLd) * sizeof(float);
+
+static hipError_t raise_lds(const void* fn, size_t bytes, bool* done) {
+    if (*done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) *done = true;
+    return e;
 }
 
 hipError_t launch_gemm_rows(const GemmRows& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (g.N > 256) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gemm_rows_kernel, dim3((unsigned)((g.M + 127) / 128)), dim3(256), 0, s, g);
+    static bool raised[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && (e = raise_lds((const void*)gemm_rows_kernel, kRowsLds, &raised[dev])) != hipSuccess) return e;
+    hipLaunchKernelGGL(gemm_rows_kernel, dim3((unsigned)((g.M + 127) / 128)), dim3(512), kRowsLds, s, g);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
-// part[slice][Mo, No(+1)] = sum over the slice's points of A[p, Mo]^T B[p, No | 1]
+// part[slice][Mo, No] = sum over the slice's points of A[p, Mo]^T B[p, No]   (dW = dY^T X)
+// dbp[slice][Mo]      = sum over the slice's points of A[p, Mo]               (db = dY^T 1)
 // One workgroup = all Mo (<= 256) rows x 128 columns; the contraction index is the point, so both tiles
-// are transposed while staging: As[m][p], Bs[n][p].
+// are transposed while staging: As[m][p], Bs[n][p]. Same loader / consumer split as gemm_rows; the bias
+// gradient costs nothing: the loader thread that stages column m of dY keeps its running sum in a register.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
-    __shared__ __attribute__((aligned(16))) float As[256 * kLd];
-    __shared__ __attribute__((aligned(16))) float Bs[128 * kLd];
+__global__ __launch_bounds__(512) void gemm_tn_kernel(GemmTN g) {
+    extern __shared__ __attribute__((aligned(16))) float lds_tn[];
+    float* As = lds_tn;                         // [2][256 * kLd]
+    float* Bs = lds_tn + 2 * 256 * kLd;         // [2][128 * kLd]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
+    const bool consumer = wave < 4;
+    const int ptid = tid & 255;
     const int slice = blockIdx.x;
     const int n0 = blockIdx.y * 128;
-    const int no_eff = g.No + (g.ones ? 1 : 0);
+    const int no_eff = g.No;
     const int64_t p_begin = (int64_t)slice * g.pts_per_slice;
     int64_t p_end = p_begin + g.pts_per_slice;
     if (p_end > g.P) p_end = g.P;
-    const int m_tiles = (g.Mo + 31) >> 5;   // <= 8
-    const int mt0 = 2 * wave, mt1 = 2 * wave + 1;
+    const int n_pt = p_end > p_begin ? (int)((p_end - p_begin + 31) / 32) : 0;
+    const int m_tiles = (g.Mo + 31) >> 5;       // <= 8
+    const int mt0 = 2 * (wave & 3), mt1 = mt0 + 1;
 
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
-
-    float ra[32], rb[16];
-    const int bn = tid & 127, bp0 = (tid >> 7) * 16;   // B staging: thread = (column, half of the 32 points)
-    auto load_tile = [&](int64_t p0) {
+    const int bn = ptid & 127, bp0 = (ptid >> 7) * 16;   // B staging: thread = (column, half of the 32 points)
+    float colsum = 0.0f;                        // loaders: sum over this slice's points of A[:, ptid]
+    auto stage = [&](int t, int buf) {
+        const int64_t p0 = p_begin + (int64_t)t * 32;
+        float* as = As + buf * 256 * kLd;
+        float* bs = Bs + buf * 128 * kLd;
+        float ra[32], rb[16];
 #pragma unroll
         for (int it = 0; it < 32; ++it) {
             const int64_t p = p0 + it;
-            ra[it] = (p < p_end && tid < g.Mo) ? g.A[p * g.lda + tid] : 0.0f;
+            ra[it] = (p < p_end && ptid < g.Mo) ? g.A[p * g.lda + ptid] : 0.0f;
         }
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int64_t p = p0 + bp0 + it;
             const int n = n0 + bn;
-            float v = 0.0f;
-            if (p < p_end) {
-                if (n < g.No) v = g.B[p * g.ldb + n];
-                else if (n == g.No && g.ones) v = 1.0f;
-            }
-            rb[it] = v;
+            rb[it] = (p < p_end && n < g.No) ? g.B[p * g.ldb + n] : 0.0f;
         }
-    };
-    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < 32; ++it) colsum += ra[it];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             f32x4 v = {ra[4 * q], ra[4 * q + 1], ra[4 * q + 2], ra[4 * q + 3]};
-            *(f32x4*)&As[tid * kLd + 4 * q] = v;
+            *(f32x4*)&as[ptid * kLd + 4 * q] = v;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 v = {rb[4 * q], rb[4 * q + 1], rb[4 * q + 2], rb[4 * q + 3]};
-            *(f32x4*)&Bs[bn * kLd + bp0 + 4 * q] = v;
+            *(f32x4*)&bs[bn * kLd + bp0 + 4 * q] = v;
         }
     };
 
-    if (p_begin < p_end) {
-        load_tile(p_begin);
-        store_tile();
+    f32x16 acc[2][4];
+    if (consumer) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
+    } else if (n_pt > 0) {
+        stage(0, 0);
     }
     __syncthreads();
-    for (int64_t p0 = p_begin; p0 < p_end; p0 += 32) {
-        const bool more = p0 + 32 < p_end;
-        if (more) load_tile(p0 + 32);
-        const F16 a0 = frag_at(As, 32 * mt0 + j, h), a1 = frag_at(As, 32 * mt1 + j, h);
-        F16 cur = frag_at(Bs, j, h);
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+    for (int t = 0; t < n_pt; ++t) {
+        if (consumer) {
+            const float* as = As + (t & 1) * 256 * kLd;
+            const float* bs = Bs + (t & 1) * 128 * kLd;
+            const F16 a0 = frag_at(as, 32 * mt0 + j, h), a1 = frag_at(as, 32 * mt1 + j, h);
+            F16 cur = frag_at(bs, j, h);
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            F16 nxt = cur;
-            if (c + 1 < 4) nxt = frag_at(Bs, 32 * (c + 1) + j, h);
-            mma_frag(acc[0][c], a0, cur);
-            SCHED_FRAG_STEP();
-            mma_frag(acc[1][c], a1, cur);
-            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-            cur = nxt;
+            for (int c = 0; c < 4; ++c) {
+                F16 nxt = cur;
+                if (c + 1 < 4) nxt = frag_at(bs, 32 * (c + 1) + j, h);
+                mma_frag(acc[0][c], a0, cur);
+                SCHED_FRAG_STEP();
+                mma_frag(acc[1][c], a1, cur);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                cur = nxt;
+            }
+        } else if (t + 1 < n_pt) {
+            stage(t + 1, (t + 1) & 1);
         }
         __syncthreads();
-        if (more) {
-            store_tile();
-            __syncthreads();
-        }
+    }
+    if (!consumer) {
+        if (g.dbp && blockIdx.y == 0 && ptid < g.Mo) g.dbp[(int64_t)slice * g.Mo + ptid] = colsum;
+        return;
     }
     float* part = g.part + (int64_t)slice * g.Mo * no_eff;
 #pragma unroll
@@ -254,27 +306,35 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN g) {
     }
 }
 
-// dW[m][n] = sum_s part[s][m][n] in slice order; column No (if present) goes to db[m]
-__global__ void reduce_slices_kernel(const float* __restrict__ part, int n_slices, int Mo, int No, int ones,
-                                     float* __restrict__ dW, int ldw, float* __restrict__ db) {
-    const int no_eff = No + (ones ? 1 : 0);
+// dW[m][n] = sum_s part[s][m][n] and db[m] = sum_s dbp[s][m], slices added in order (deterministic)
+__global__ void reduce_slices_kernel(const float* __restrict__ part, const float* __restrict__ dbp, int n_slices,
+                                     int Mo, int No, float* __restrict__ dW, int ldw, float* __restrict__ db) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)Mo * no_eff) return;
-    const int m = (int)(idx / no_eff), n = (int)(idx % no_eff);
-    float s = 0.0f;
-    for (int k = 0; k < n_slices; ++k) s += part[(int64_t)k * Mo * no_eff + idx];
-    if (n < No) dW[(int64_t)m * ldw + n] = s;
-    else if (db) db[m] = s;
+    const int64_t n_w = (int64_t)Mo * No;
+    if (idx < n_w) {
+        float s = 0.0f;
+        for (int k = 0; k < n_slices; ++k) s += part[(int64_t)k * n_w + idx];
+        dW[(idx / No) * ldw + (idx % No)] = s;
+    } else if (idx < n_w + Mo && db && dbp) {
+        const int m = (int)(idx - n_w);
+        float s = 0.0f;
+        for (int k = 0; k < n_slices; ++k) s += dbp[(int64_t)k * Mo + m];
+        db[m] = s;
+    }
 }
 
 hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, float* db, hipStream_t s) {
     if (g.Mo <= 0 || g.No <= 0) return hipSuccess;
     if (g.Mo > 256) return hipErrorInvalidValue;
-    const int no_eff = g.No + (g.ones ? 1 : 0);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)n_slices, (unsigned)((no_eff + 127) / 128)), dim3(256), 0, s, g);
-    const int64_t total = (int64_t)g.Mo * no_eff;
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g.part, n_slices,
-                       g.Mo, g.No, g.ones, dW, ldw, db);
+    static bool raised[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && (e = raise_lds((const void*)gemm_tn_kernel, kTnLds, &raised[dev])) != hipSuccess) return e;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)n_slices, (unsigned)((g.No + 127) / 128)), dim3(512), kTnLds, s, g);
+    const int64_t total = (int64_t)g.Mo * g.No + g.Mo;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g.part, g.dbp, n_slices,
+                       g.Mo, g.No, dW, ldw, db);
     return hipGetLastError();
 }
 
