@@ -494,15 +494,17 @@ def test_train_gradients_match_autograd(N, weights_pair):
     g, net_c, net_f, kw, batch_rays, target = _train_setup(N, weights_pair)
     opt = N.Adam([net_c, net_f], lr=5e-4)
     out = N.train_on_batch(800, 800, None, batch_rays, target, opt, apply_update=False, **kw)
-    assert abs(float(out["img_loss"]) - float(g["img_loss_0"])) <= 2e-5
+    assert abs(float(out["img_loss"]) - float(g["img_loss_0"])) <= 2e-6
     assert abs(float(out["img_loss0"]) - float(g["img_loss0_0"])) <= 2e-6
-    assert abs(float(out["loss"]) - float(g["img_loss_0"]) - float(g["img_loss0_0"])) <= 2e-5
+    assert abs(float(out["loss"]) - float(g["img_loss_0"]) - float(g["img_loss0_0"])) <= 4e-6
     for tag, net in (("c", net_c), ("f", net_f)):
         grads = net.grad_dict()
         for k, gr in grads.items():
             gr = gr.numpy().reshape(-1)
             want_norm, want_sub = float(g[f"gnorm_{tag}.{k}"]), g[f"gsub_{tag}.{k}"]
-            tol = 2e-3 if tag == "c" else 2e-2         # the fine pass inherits the resampling sensitivity
+            # measured on MI355X: norms within 4e-7 (coarse) / 2e-6 (fine), elements within 5e-6 / 3e-5 of the
+            # tensor's largest gradient; the fine pass inherits the resampling sensitivity of the forward pass
+            tol = 2e-5 if tag == "c" else 2e-4
             assert abs(np.linalg.norm(gr.astype(np.float64)) - want_norm) <= tol * want_norm + 1e-9, (tag, k)
             scale = np.abs(want_sub).max() + 1e-12
             assert np.abs(gr[::61] - want_sub).max() <= 5 * tol * scale + 1e-9, (tag, k)
