@@ -67,6 +67,20 @@ int nerf_device_count(void);
 int nerf_ctx_create(int device, nerf_ctx** out);
 void nerf_ctx_destroy(nerf_ctx* ctx);
 
+/* Arithmetic of the fused encode+MLP kernel (NeRF.forward, nerf/nerf.py:57-111). Inputs, outputs, biases,
+ * activations between layers and everything outside the MLP are fp32 in both modes (the reference sets
+ * torch.float32, nerf.ipynb:76); the modes differ in how the 256-wide contractions are evaluated:
+ *   NERF_PRECISION_F32    v_mfma_f32_32x32x2_f32: an fp32 fmaf chain (24-bit operands).
+ *   NERF_PRECISION_F16X2  every operand split exactly into two fp16 numbers (22 bits), scaled per layer
+ *                         (weights) and per point (activations) by powers of two, three
+ *                         v_mfma_f32_32x32x16_f16 products per term, fp32 accumulation. Error of a
+ *                         256-long dot product: 0.5-1.0 eps(fp32) rms vs 0.4-0.5 for the fmaf chain.
+ * Takes effect for the following calls on this context; weights loaded earlier stay valid. */
+#define NERF_PRECISION_F32 0
+#define NERF_PRECISION_F16X2 1
+int nerf_set_precision(nerf_ctx* ctx, int precision);
+int nerf_get_precision(nerf_ctx* ctx);
+
 /* Weights ---------------------------------------------------------------------------
  * Replaces NeRF.__init__ + load_state_dict (nerf/nerf.py:9-55; checkpoint reload at
  * nerf.ipynb:927-935). `tensors` are host pointers to the state_dict entries in this

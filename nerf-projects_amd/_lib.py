@@ -17,7 +17,8 @@ EXPORTS = (
     "nerf_load_weights", "nerf_num_weight_tensors", "nerf_embed", "nerf_mlp_forward", "nerf_run_network",
     "nerf_raw2outputs", "nerf_sample_pdf", "nerf_render_rays", "nerf_profile_enable", "nerf_profile_read",
     "nerf_workspace_bytes", "nerf_generate_rays", "nerf_image_metrics", "nerf_train_step", "nerf_get_weights",
-    "nerf_get_gradients", "nerf_stratified_z", "nerf_resample", "nerf_render_frame",
+    "nerf_get_gradients", "nerf_stratified_z", "nerf_resample", "nerf_render_frame", "nerf_set_precision",
+    "nerf_get_precision",
 )
 
 
@@ -131,6 +132,10 @@ def load():
     lib.nerf_render_frame.argtypes = [vp, C.POINTER(FrameArgs)]
     lib.nerf_workspace_bytes.restype = i64
     lib.nerf_workspace_bytes.argtypes = [vp]
+    lib.nerf_set_precision.restype = i32
+    lib.nerf_set_precision.argtypes = [vp, i32]
+    lib.nerf_get_precision.restype = i32
+    lib.nerf_get_precision.argtypes = [vp]
     _lib = lib
     return lib
 

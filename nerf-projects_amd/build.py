@@ -8,23 +8,27 @@ cross the boundary (include/nerf_mi355x.h).
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnerf_mi355x.so")
-SOURCES = ["api.cpp", "train_api.cpp", "pack_weights.cpp", "mlp_kernel.hip", "ray_kernels.hip", "train_kernels.hip"]
+SOURCES = ["api.cpp", "train_api.cpp", "pack_weights.cpp", "mlp_kernel.hip", "mlp_kernel_h2.hip", "ray_kernels.hip",
+           "train_kernels.hip"]
 HEADERS = [os.path.join(CSRC, "nerf_internal.h"), os.path.join(CSRC, "ctx_internal.h"),
-           os.path.join(ROOT, "include", "nerf_mi355x.h")]
+           os.path.join(CSRC, "mlp_inputs.h"), os.path.join(ROOT, "include", "nerf_mi355x.h")]
 FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
+    "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17",
     "-ffp-contract=off",          # PyTorch's op boundaries are rounding boundaries; fmaf is explicit where wanted
     "-fno-fast-math", "-Wall", "-Wno-unused-function",
-    # keep MFMA results in arch VGPRs where the allocator can: the per-layer ReLU then needs no
-    # v_accvgpr_read per element (578 -> 163 in the MLP kernel, +1.1 % frame rate, measured A/B)
-    "-mllvm", "-amdgpu-mfma-vgpr-form",
     "-x", "hip",
 ]
+# keep MFMA results in arch VGPRs where the allocator can: the per-layer ReLU then needs no
+# v_accvgpr_read per element (578 -> 163 in the fp32 MLP kernel, +1.1 % frame rate, measured A/B).
+# The fp16-pair kernel holds 128 accumulators + 176 operand registers and needs the AGPR half for the former.
+VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+EXTRA = {"mlp_kernel_h2.hip": []}
 
 
 def hipcc():
@@ -45,15 +49,29 @@ def up_to_date():
 def build(force=False, keep_temps=False, verbose=True):
     if not force and up_to_date():
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
-    if keep_temps:
-        tmp = os.path.join(HERE, "build")
-        os.makedirs(tmp, exist_ok=True)
-        cmd += ["-save-temps=cwd", "-Rpass-analysis=kernel-resource-usage"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    tmp = os.path.join(HERE, "build")
+    os.makedirs(tmp, exist_ok=True)
+    only = os.environ.get("NERF_BUILD_ONLY")      # e.g. "mlp_kernel_h2.hip": recompile just that object
+
+    def compile_one(src):
+        obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
+        if only and src not in only.split(",") and os.path.exists(obj):
+            return obj
+        cmd = [hipcc()] + FLAGS + EXTRA.get(src, VGPR_FORM) + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+        if keep_temps:
+            cmd += ["-save-temps=cwd", "-Rpass-analysis=kernel-resource-usage"]
+        cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=tmp)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=os.path.join(HERE, "build") if keep_temps else HERE)
+        print(" ".join(link), flush=True)
+    subprocess.run(link, check=True, cwd=tmp)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

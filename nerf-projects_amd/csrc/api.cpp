@@ -31,6 +31,8 @@ namespace {
 
 int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net, int mode, hipStream_t s) {
     a.stream = net.d_stream;
+    a.stream_h2 = net.d_stream_h2;
+    a.descale = net.d_descale;
     a.bias = net.d_bias;
     a.n_chunks = net.n_chunks;
     a.n_bias_tiles = net.n_bias_tiles;
@@ -52,7 +54,10 @@ int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net, int mode, hipStream
         }
         HIP_TRY(hipEventRecord(e0, s));
     }
-    HIP_TRY(launch_mlp(a, mode, s));
+    if (c->precision == NERF_PRECISION_F16X2)
+        HIP_TRY(launch_mlp_h2(a, mode, s));
+    else
+        HIP_TRY(launch_mlp(a, mode, s));
     if (c->profiling) {
         HIP_TRY(hipEventRecord(e1, s));
         c->events.emplace_back(e0, e1);
@@ -64,7 +69,8 @@ int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net, int mode, hipStream
 void free_net(PackedNet& n) {
     for (void* p : {(void*)n.d_stream, (void*)n.d_bias, (void*)n.d_params, (void*)n.train.d_grad, (void*)n.train.d_m,
                     (void*)n.train.d_v, (void*)n.train.d_wt, (void*)n.train.d_stream_table,
-                    (void*)n.train.d_bias_table})
+                    (void*)n.train.d_bias_table, (void*)n.d_stream_h2, (void*)n.d_descale, (void*)n.d_chunk_layer,
+                    (void*)n.d_chunk_max})
         if (p) (void)hipFree(p);
     n = PackedNet{};
 }
@@ -175,6 +181,17 @@ void nerf_ctx_destroy(nerf_ctx* c) {
     delete c;
 }
 
+int nerf_set_precision(nerf_ctx* c, int precision) {
+    if (!c || (precision != NERF_PRECISION_F32 && precision != NERF_PRECISION_F16X2)) {
+        set_error("nerf_set_precision: invalid argument");
+        return NERF_E_INVALID;
+    }
+    c->precision = precision;
+    return NERF_OK;
+}
+
+int nerf_get_precision(nerf_ctx* c) { return c ? c->precision : NERF_E_INVALID; }
+
 int nerf_load_weights(nerf_ctx* c, int slot, const nerf_arch* arch, const float* const* tensors, int n_tensors) {
     if (!c || !arch || !tensors) {
         set_error("nerf_load_weights: NULL argument");
@@ -243,6 +260,22 @@ int nerf_load_weights(nerf_ctx* c, int slot, const nerf_arch* arch, const float*
         e = hipMemcpy(net.d_bias, hb, (size_t)nbt * kBiasTileFloats * sizeof(float), hipMemcpyHostToDevice);
     free(hs);
     free(hb);
+    // fp16-pair twin of the stream (NERF_PRECISION_F16X2), converted on the device
+    const std::vector<int> layer_of = chunk_layers(*arch, mask);
+    if (e == hipSuccess && (int)layer_of.size() != nc) {
+        set_error("internal: %zu chunk scale groups for %d chunks", layer_of.size(), nc);
+        return NERF_E_INVALID;
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&net.d_stream_h2, (size_t)nc * kChunkBytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&net.d_descale, (kMaxDepth + 2) * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&net.d_chunk_layer, (size_t)nc * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&net.d_chunk_max, (size_t)nc * sizeof(float));
+    if (e == hipSuccess)
+        e = hipMemcpy(net.d_chunk_layer, layer_of.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = launch_convert_stream_h2(net.d_stream, net.d_chunk_layer, nc, net.d_chunk_max, net.d_stream_h2,
+                                     net.d_descale, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         set_error("uploading packed weights failed: %s", hipGetErrorString(e));
         return NERF_E_HIP;

@@ -53,6 +53,12 @@ struct PackedNet {
     TrainState train;
     float* d_stream = nullptr;   // n_chunks * kChunkFloats
     float* d_bias = nullptr;     // n_bias_tiles * kBiasTileFloats
+    // fp16-pair twin of d_stream (mlp_kernel_h2.hip): same chunks, every weight as (hi, lo) halves
+    // scaled by its layer's power of two; d_descale[layer] undoes the scale
+    uint32_t* d_stream_h2 = nullptr;
+    float* d_descale = nullptr;
+    int* d_chunk_layer = nullptr;
+    float* d_chunk_max = nullptr;
     int n_chunks = 0;
     int n_bias_tiles = 0;
     uint32_t skip_in_mask = 0;   // bit i: trunk layer i reads [input_pts, h]
@@ -63,6 +69,8 @@ enum MlpInputMode { kInputEmbedded = 0, kInputPoints = 1, kInputRays = 2 };
 
 struct MlpLaunch {
     const float* stream;
+    const uint32_t* stream_h2;   // NERF_PRECISION_F16X2 only
+    const float* descale;
     const float* bias;
     int n_chunks;
     int n_bias_tiles;
@@ -92,8 +100,14 @@ int pack_weights(const nerf_arch& arch, const float* const* tensors, int n_tenso
                  float** stream_out, int* n_chunks, float** bias_out, int* n_bias_tiles,
                  uint32_t* skip_in_mask, int* out_ch);
 
-// kernel launchers (mlp_kernel.hip, ray_kernels.hip)
+// scale group ("layer") of every chunk of the stream, in stream order
+std::vector<int> chunk_layers(const nerf_arch& arch, uint32_t skip_in_mask);
+
+// kernel launchers (mlp_kernel.hip, mlp_kernel_h2.hip, ray_kernels.hip)
 hipError_t launch_mlp(const MlpLaunch& a, int mode, hipStream_t s);
+hipError_t launch_mlp_h2(const MlpLaunch& a, int mode, hipStream_t s);
+hipError_t launch_convert_stream_h2(const float* stream, const int* chunk_layer, int n_chunks, float* chunk_max,
+                                    uint32_t* out, float* descale, hipStream_t s);
 hipError_t launch_embed(const float* x, int64_t n, int multires, float* out, hipStream_t s);
 hipError_t launch_stratified(const float* rays, int ray_ld, int64_t N, int S, int lindisp,
                              const float* t_rand, float* z_vals, hipStream_t s);

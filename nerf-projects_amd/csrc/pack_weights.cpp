@@ -92,6 +92,23 @@ void row_tiles(std::vector<float>& out, const Linear& L, int row, int n_kt) {
 
 }  // namespace
 
+// Mirrors the chunk order pack_weights emits below: trunk layer i (its encoding chunks first when it reads
+// cat[input_pts, h]), then feature_linear (id D) and views_linears.0 (id D+1), or output_linear (id D).
+std::vector<int> chunk_layers(const nerf_arch& a, uint32_t mask) {
+    std::vector<int> ids;
+    for (int i = 0; i < a.D; ++i) {
+        const bool pe_in = (i == 0) || (mask >> i & 1);
+        ids.insert(ids.end(), (pe_in ? 2 : 0) + (i > 0 ? 8 : 0), i);
+    }
+    if (a.use_viewdirs) {
+        ids.insert(ids.end(), 8, a.D);
+        ids.insert(ids.end(), 5, a.D + 1);
+    } else {
+        ids.insert(ids.end(), 1, a.D);
+    }
+    return ids;
+}
+
 int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors, float** stream_out,
                  int* n_chunks, float** bias_out, int* n_bias_tiles, uint32_t* skip_in_mask,
                  int* out_ch) {

@@ -11,6 +11,7 @@ gfx950 GPU every entry point raises.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -43,6 +44,21 @@ class Context:
         check(lib.nerf_ctx_create(device_index, C.byref(handle)))
         self.handle = handle
         self._slots = [None] * _lib.NERF_NUM_SLOTS
+        default = os.environ.get("NERF_PRECISION")
+        if default:
+            self.set_precision(default)
+
+    PRECISIONS = {"f32": 0, "f16x2": 1}
+
+    def set_precision(self, name):
+        """Arithmetic of the fused MLP kernel: "f32" (fp32 MFMA) or "f16x2" (exact fp16-pair split, 3 MFMAs per term)."""
+        if name not in self.PRECISIONS:
+            raise ValueError(f"precision {name!r}: expected one of {sorted(self.PRECISIONS)}")
+        check(self.lib.nerf_set_precision(self.handle, self.PRECISIONS[name]))
+
+    def get_precision(self):
+        code = self.lib.nerf_get_precision(self.handle)
+        return {v: k for k, v in self.PRECISIONS.items()}[code]
 
     def alloc_slot(self, owner):
         for i, o in enumerate(self._slots):
