@@ -58,6 +58,7 @@ def build(force=False, keep_temps=False, verbose=True):
         if only and src not in only.split(",") and os.path.exists(obj):
             return obj
         cmd = [hipcc()] + FLAGS + EXTRA.get(src, VGPR_FORM) + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+        cmd += os.environ.get("NERF_EXTRA_FLAGS", "").split()       # ablation builds (-DNERF_ABLATE_...)
         if keep_temps:
             cmd += ["-save-temps=cwd", "-Rpass-analysis=kernel-resource-usage"]
         cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
@@ -68,12 +69,13 @@ def build(force=False, keep_temps=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as pool:
         objs = list(pool.map(compile_one, SOURCES))
-    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
+    out = os.environ.get("NERF_LIB_OUT", LIB)                       # ablation builds go next to the real library
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out + ".tmp"]
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.run(link, check=True, cwd=tmp)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":

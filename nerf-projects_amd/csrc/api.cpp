@@ -33,6 +33,7 @@ int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net, int mode, hipStream
     a.stream = net.d_stream;
     a.stream_h2 = net.d_stream_h2;
     a.descale = net.d_descale;
+    a.gain = net.d_gain;
     a.bias = net.d_bias;
     a.n_chunks = net.n_chunks;
     a.n_bias_tiles = net.n_bias_tiles;
@@ -66,11 +67,30 @@ int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net, int mode, hipStream
     return NERF_OK;
 }
 
+}  // namespace
+
+namespace nerf {
+GainRefs gain_refs(const nerf_arch& a, const std::vector<LinearDesc>& linears) {
+    GainRefs r{};
+    r.n = a.use_viewdirs ? a.D + 1 : a.D;
+    for (int l = 0; l < r.n; ++l) {
+        const LinearDesc& d = linears[l < a.D ? l : a.D + 1];   // feature_linear follows views_linears.0
+        r.w_off[l] = d.w_off;
+        r.b_off[l] = d.b_off;
+        r.out[l] = d.out;
+        r.in[l] = d.in;
+    }
+    return r;
+}
+}  // namespace nerf
+
+namespace {
+
 void free_net(PackedNet& n) {
     for (void* p : {(void*)n.d_stream, (void*)n.d_bias, (void*)n.d_params, (void*)n.train.d_grad, (void*)n.train.d_m,
                     (void*)n.train.d_v, (void*)n.train.d_wt, (void*)n.train.d_stream_table,
                     (void*)n.train.d_bias_table, (void*)n.d_stream_h2, (void*)n.d_descale, (void*)n.d_chunk_layer,
-                    (void*)n.d_chunk_max})
+                    (void*)n.d_chunk_max, (void*)n.d_gain})
         if (p) (void)hipFree(p);
     n = PackedNet{};
 }
@@ -275,6 +295,8 @@ int nerf_load_weights(nerf_ctx* c, int slot, const nerf_arch* arch, const float*
     if (e == hipSuccess)
         e = launch_convert_stream_h2(net.d_stream, net.d_chunk_layer, nc, net.d_chunk_max, net.d_stream_h2,
                                      net.d_descale, nullptr);
+    if (e == hipSuccess) e = hipMalloc((void**)&net.d_gain, 2 * (kMaxDepth + 2) * sizeof(float));
+    if (e == hipSuccess) e = launch_layer_gains(net.d_params, gain_refs(*arch, net.linears), net.d_gain, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         set_error("uploading packed weights failed: %s", hipGetErrorString(e));

@@ -279,13 +279,13 @@ void nerf_mlp_kernel(const MlpLaunch a) {
             sigma = row_dot<8>(hid, bias_lds, 8 * a.D + 14, h) + bias_lds[(8 * a.D) * 32];
         }
         load_bias<8>(acc, bias_lds, is_feature ? 8 * a.D + 1 : 8 * i, h);
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) chunk_ktile8(pipe, cur, acc, hid[kt]);
         if (!is_feature && ((a.skip_in_mask >> i) & 1)) {
             // h = cat[input_pts, h] (nerf.py:79-80): the encoded inputs are still in registers
             chunk_ktile8(pipe, cur, acc, x0);
             chunk_ktile8(pipe, cur, acc, x1);
         }
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt) chunk_ktile8(pipe, cur, acc, hid[kt]);
         if (is_feature) activate<8, false>(hid, acc); else activate<8, true>(hid, acc);
     }
 

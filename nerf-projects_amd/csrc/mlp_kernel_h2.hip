@@ -83,13 +83,21 @@ __device__ __forceinline__ Frag4 read_frags(const f32x4* fr, int group) {
     return f;
 }
 
-// the six products of one step, small terms first
+// the six products of one step, small terms first; PART 0 = the first product, PART 1 = the other five
+template <int PART>
 __device__ __forceinline__ void mma_step(f32x16& acc, const Frag4& f, const XT& x) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        acc = mma(f.q[2 * s + 1], x.hi[s], acc);
-        acc = mma(f.q[2 * s], x.lo[s], acc);
-        acc = mma(f.q[2 * s], x.hi[s], acc);
+    if constexpr (PART == 0) {
+        acc = mma(f.q[1], x.hi[0], acc);
+    } else {
+#ifndef NERF_ABLATE_MFMA
+        acc = mma(f.q[0], x.lo[0], acc);
+#endif
+        acc = mma(f.q[0], x.hi[0], acc);
+#ifndef NERF_ABLATE_MFMA
+        acc = mma(f.q[3], x.hi[1], acc);
+        acc = mma(f.q[2], x.lo[1], acc);
+#endif
+        acc = mma(f.q[2], x.hi[1], acc);
     }
 }
 
@@ -97,18 +105,30 @@ template <int S>
 struct StepTag {
     static constexpr int value = S;
 };
+template <int P>
+struct PartTag {
+    static constexpr int value = P;
+};
 
 // Consume the current chunk in NSTEP steps of 6 MFMAs; `cur` holds the fragments of step 0 on entry and
-// of the NEXT chunk's step 0 on exit. Fragment reads of step n+1 are issued behind the first MFMA of step n.
+// of the NEXT chunk's step 0 on exit. One wave per SIMD has nobody to hide LDS latency behind, so the order
+// is pinned with scheduling fences: first MFMA of step n, the four fragment reads of step n+1 (into the
+// other half of a double buffer), the other five MFMAs (160 matrix-pipe cycles for the reads to return).
+// Left to itself hipcc sinks the reads below the step's last MFMA to share registers and waits for them.
 template <int S, int NSTEP, class Body>
 __device__ __forceinline__ void run_steps(PipeH& p, Frag4& cur, const f32x4* fr, const f32x4* fr_next, Body& body) {
     if constexpr (S < NSTEP) {
+        body(StepTag<S>{}, PartTag<0>{}, cur);
+        __builtin_amdgcn_sched_barrier(0);
         Frag4 nxt = (S + 1 < NSTEP) ? read_frags(fr, (S + 1) * 4) : read_frags(fr_next, 0);
-        body(StepTag<S>{}, cur);
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (S == NSTEP / 2) {
-            // the step after the barrier also issues the 8 LDS-DMA pieces of chunk c+3
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            // the step after the barrier also issues the 8 LDS-DMA pieces of chunk c+3, two per MFMA
+            const int nx = p.c + 3 < p.n ? p.c + 3 : p.c + 3 - p.n;   // wraps into the next tile's stream
+#ifndef NERF_ABLATE_DMA
+            prefetch_chunk(p, nx, ringh_next(p.b, 3));
+#endif
+            body(StepTag<S>{}, PartTag<1>{}, cur);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -116,16 +136,13 @@ __device__ __forceinline__ void run_steps(PipeH& p, Frag4& cur, const f32x4* fr,
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+            body(StepTag<S>{}, PartTag<1>{}, cur);
         }
+        __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
         if constexpr (S == NSTEP / 2 - 1) {
-            __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-            const int nx = p.c + 3 < p.n ? p.c + 3 : p.c + 3 - p.n;   // wraps into the next tile's stream
-            prefetch_chunk(p, nx, ringh_next(p.b, 3));
+            __builtin_amdgcn_sched_barrier(0);
         }
         run_steps<S + 1, NSTEP>(p, cur, fr, fr_next, body);
     }
@@ -143,20 +160,26 @@ __device__ __forceinline__ void consume_chunk(PipeH& p, Frag4& cur, Body body) {
 // chunk kinds: the group order is the fp32 stream's (pack_weights.cpp) with each unit of four groups
 // re-cut into [k-slice][hi|lo] by convert_stream_h2 below
 __device__ __forceinline__ void chunk_ktile8(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x) {
-    consume_chunk<8>(p, cur, [&](auto tag, const Frag4& f) { mma_step(acc[decltype(tag)::value], f, x); });
+    consume_chunk<8>(p, cur, [&](auto tag, auto part, const Frag4& f) {
+        mma_step<decltype(part)::value>(acc[decltype(tag)::value], f, x);
+    });
 }
 __device__ __forceinline__ void chunk_ktile4(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x) {
-    consume_chunk<4>(p, cur, [&](auto tag, const Frag4& f) { mma_step(acc[decltype(tag)::value], f, x); });
+    consume_chunk<4>(p, cur, [&](auto tag, auto part, const Frag4& f) {
+        mma_step<decltype(part)::value>(acc[decltype(tag)::value], f, x);
+    });
 }
 __device__ __forceinline__ void chunk_pair4(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x0, const XT& x1) {
-    consume_chunk<8>(p, cur, [&](auto tag, const Frag4& f) {
+    consume_chunk<8>(p, cur, [&](auto tag, auto part, const Frag4& f) {
         constexpr int s = decltype(tag)::value;
-        mma_step(acc[s & 3], f, s < 4 ? x0 : x1);
+        mma_step<decltype(part)::value>(acc[s & 3], f, s < 4 ? x0 : x1);
     });
 }
 template <int NKT>
 __device__ __forceinline__ void chunk_row(PipeH& p, Frag4& cur, f32x16& acc, const XT (&x)[8]) {
-    consume_chunk<NKT>(p, cur, [&](auto tag, const Frag4& f) { mma_step(acc, f, x[decltype(tag)::value]); });
+    consume_chunk<NKT>(p, cur, [&](auto tag, auto part, const Frag4& f) {
+        mma_step<decltype(part)::value>(acc, f, x[decltype(tag)::value]);
+    });
 }
 
 // ---- per-point scaling and the fp16 split --------------------------------------------------------
@@ -185,6 +208,10 @@ __device__ __forceinline__ h16x2 round_pair(float a, float b) {
 
 // v * sc -> (hi, lo) for the 16 registers of one tile
 __device__ __forceinline__ void split_tile(XT& out, const f32x16& v, float sc) {
+#ifdef NERF_ABLATE_SPLIT
+    out.hi[0][0] = __float_as_uint(v[0] * sc);
+    return;
+#endif
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -213,18 +240,49 @@ __device__ __forceinline__ void rescale_tile(XT& x, int d) {
         }
 }
 
+// 64 bytes of the bias block per lane. hipcc guards every LDS load it can see with s_waitcnt vmcnt(0) while an
+// LDS-DMA write is in flight (it cannot tell the bias block from the ring), which would drain the weight pipeline
+// twice per layer; these reads are therefore issued from inline asm, with their own lgkmcnt wait (LDS returns in
+// order, and the waits hipcc computes for its own reads can only become stricter by the extra entries).
+struct Tile16 {
+    f32x4 q[4];
+};
+__device__ __forceinline__ Tile16 lds_tile_issue(const float* p) {
+    Tile16 t;
+    const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+    asm volatile(
+        "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+        "ds_read_b128 %3, %4 offset:48"
+        : "=&v"(t.q[0]), "=&v"(t.q[1]), "=&v"(t.q[2]), "=&v"(t.q[3])
+        : "v"(addr)
+        : "memory");
+    return t;
+}
+__device__ __forceinline__ void lds_tile_wait(Tile16& t) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t.q[0]), "+v"(t.q[1]), "+v"(t.q[2]), "+v"(t.q[3])::"memory");
+}
+__device__ __forceinline__ float lds_scalar(const float* p) {
+    float v;
+    const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
 // y = acc * c + bias (and ReLU above `floor`); returns this lane's largest |y|
 template <int N>
 __device__ __forceinline__ float finish_layer(f32x16 (&y)[8], const f32x16 (&acc)[8], const float* bias_lds, int tile,
                                               int h, float c, float floor) {
     float m0 = 0.0f, m1 = 0.0f;
+    Tile16 nxt = lds_tile_issue(bias_lds + (tile * 2 + h) * 16);
 #pragma unroll
     for (int t = 0; t < N; ++t) {
-        const f32x16 b = *(const f32x16*)(bias_lds + ((tile + t) * 2 + h) * 16);
+        Tile16 b = nxt;
+        lds_tile_wait(b);
+        if (t + 1 < N) nxt = lds_tile_issue(bias_lds + ((tile + t + 1) * 2 + h) * 16);
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            const float v0 = fmaxf(fmaf(acc[t][r], c, b[r]), floor);
-            const float v1 = fmaxf(fmaf(acc[t][r + 1], c, b[r + 1]), floor);
+            const float v0 = fmaxf(fmaf(acc[t][r], c, b.q[r >> 2][r & 3]), floor);
+            const float v1 = fmaxf(fmaf(acc[t][r + 1], c, b.q[(r + 1) >> 2][(r + 1) & 3]), floor);
             y[t][r] = v0;
             y[t][r + 1] = v1;
             m0 = fmaxf(m0, fabsf(v0));
@@ -246,13 +304,16 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&acc)[8]) {
 template <int NKT>
 __device__ __forceinline__ float row_dot(const f32x16 (&x)[8], const float* bias_lds, int tile, int h) {
     float s0 = 0.0f, s1 = 0.0f;
+    Tile16 nxt = lds_tile_issue(bias_lds + (tile * 2 + h) * 16);
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-        const f32x16 w = *(const f32x16*)(bias_lds + ((tile + kt) * 2 + h) * 16);
+        Tile16 w = nxt;
+        lds_tile_wait(w);
+        if (kt + 1 < NKT) nxt = lds_tile_issue(bias_lds + ((tile + kt + 1) * 2 + h) * 16);
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            s0 = fmaf(w[r], x[kt][r], s0);
-            s1 = fmaf(w[r + 1], x[kt][r + 1], s1);
+            s0 = fmaf(w.q[r >> 2][r & 3], x[kt][r], s0);
+            s1 = fmaf(w.q[(r + 1) >> 2][(r + 1) & 3], x[kt][r + 1], s1);
         }
     }
     const float s = s0 + s1;
@@ -263,18 +324,23 @@ __device__ __forceinline__ float row_dot(const f32x16 (&x)[8], const float* bias
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void nerf_mlp_h2_kernel(const MlpLaunch a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* bias_lds = (float*)smem;
+    // The ring is the dynamic LDS allocation, the bias block a separate static one: hipcc guards every LDS read that
+    // may alias an in-flight LDS-DMA write with s_waitcnt vmcnt(0), which would drain the weight pipeline at each
+    // bias read; two distinct LDS objects cannot alias.
+    extern __shared__ __attribute__((aligned(16))) char ring_lds[];
+    __shared__ __attribute__((aligned(16))) float bias_lds[kBiasLdsBytes / 4];
+    __shared__ float descale_lds[kMaxDepth + 2];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
 
-    PipeH pipe{(const char*)a.stream_h2, smem + kBiasLdsBytes, 0, 0, a.n_chunks, wave, lane};
+    PipeH pipe{(const char*)a.stream_h2, ring_lds, 0, 0, a.n_chunks, wave, lane};
     prefetch_chunk(pipe, 0, 0);
     prefetch_chunk(pipe, 1, 1);
     prefetch_chunk(pipe, 2, 2);
     for (int i = threadIdx.x; i < a.n_bias_tiles * kBiasTileFloats; i += 256) bias_lds[i] = a.bias[i];
-    __syncthreads();   // chunks 0..2 and the bias block are in LDS
+    if (threadIdx.x < a.D + 2) descale_lds[threadIdx.x] = a.descale[threadIdx.x];
+    __syncthreads();   // chunks 0..2, the bias block and the layer scales are in LDS
     Frag4 cur = read_frags(ring_frags(pipe, 0), 0);
 
     const int64_t n_tiles = (a.n_points + kPointsPerGroup - 1) / kPointsPerGroup;
@@ -310,8 +376,8 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
         chunk_ktile8(pipe, cur, acc, xp0);
         chunk_ktile8(pipe, cur, acc, xp1);
         {
-            float m = half_max(finish_layer<8>(y, acc, bias_lds, 0, h, a.descale[0] * pow2f(-t_pe), 0.0f));
-            if (a.D == 1 && a.use_viewdirs) sigma = row_dot<8>(y, bias_lds, 8 * a.D + 14, h) + bias_lds[(8 * a.D) * 32];
+            float m = half_max(finish_layer<8>(y, acc, bias_lds, 0, h, lds_scalar(descale_lds) * pow2f(-t_pe), 0.0f));
+            if (a.D == 1 && a.use_viewdirs) sigma = row_dot<8>(y, bias_lds, 8 * a.D + 14, h) + lds_scalar(bias_lds + (8 * a.D) * 32);
             if ((a.skip_in_mask >> 1) & 1) m = fmaxf(m, m_pe);
             t_cur = pick_exponent(m);
             const float sc = pow2f(t_cur);
@@ -323,7 +389,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
         const int n_layers = a.use_viewdirs ? a.D + 1 : a.D;
         for (int i = 1; i < n_layers; ++i) {
             const bool is_feature = (i == a.D);
-            const float c = a.descale[i] * pow2f(-t_cur);
+            const float c = lds_scalar(descale_lds + i) * pow2f(-t_cur);
             zero_tiles<8>(acc);
             if (!is_feature && ((a.skip_in_mask >> i) & 1)) {
                 // h = cat[input_pts, h] (nerf.py:79-80): bring the encoded inputs to this layer's scale
@@ -339,7 +405,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
                                                is_feature ? -__builtin_inff() : 0.0f));
             if (i == a.D - 1 && a.use_viewdirs) {
                 // alpha_linear reads the post-ReLU trunk output (nerf.py:86): one row, as a dot product
-                sigma = row_dot<8>(y, bias_lds, 8 * a.D + 14, h) + bias_lds[(8 * a.D) * 32];
+                sigma = row_dot<8>(y, bias_lds, 8 * a.D + 14, h) + lds_scalar(bias_lds + (8 * a.D) * 32);
             }
             if (is_feature) m = fmaxf(m, m_dd);
             else if ((a.skip_in_mask >> (i + 1)) & 1) m = fmaxf(m, m_pe);
@@ -357,12 +423,12 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
 #pragma unroll
             for (int kp = 0; kp < 4; ++kp) chunk_pair4(pipe, cur, acc, hid[2 * kp], hid[2 * kp + 1]);
             chunk_ktile4(pipe, cur, acc, xd);
-            finish_layer<4>(y, acc, bias_lds, 8 * a.D + 9, h, a.descale[a.D + 1] * pow2f(-t_cur), 0.0f);
+            finish_layer<4>(y, acc, bias_lds, 8 * a.D + 9, h, lds_scalar(descale_lds + a.D + 1) * pow2f(-t_cur), 0.0f);
             // rgb_linear (nerf.py:101): three rows over the 128-wide view layer
             const float* rb = bias_lds + (8 * a.D + 13) * 32;
-            const float r0 = row_dot<4>(y, bias_lds, 8 * a.D + 22, h) + rb[0];
-            const float r1 = row_dot<4>(y, bias_lds, 8 * a.D + 26, h) + rb[1];
-            const float r2 = row_dot<4>(y, bias_lds, 8 * a.D + 30, h) + rb[2];
+            const float r0 = row_dot<4>(y, bias_lds, 8 * a.D + 22, h) + lds_scalar(rb);
+            const float r1 = row_dot<4>(y, bias_lds, 8 * a.D + 26, h) + lds_scalar(rb + 1);
+            const float r2 = row_dot<4>(y, bias_lds, 8 * a.D + 30, h) + lds_scalar(rb + 2);
             if (live && h == 0) {
                 f32x4 o = {r0, r1, r2, sigma};   // outputs = cat[rgb, alpha] (nerf.py:106)
                 *(f32x4*)(a.out + pt * 4) = o;
@@ -373,13 +439,14 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = 0.0f;
             chunk_row<8>(pipe, cur, o, hid);
-            const f32x16 b = *(const f32x16*)(bias_lds + ((8 * a.D) * 2 + h) * 16);
-            const float c = a.descale[a.D] * pow2f(-t_cur);
+            Tile16 b = lds_tile_issue(bias_lds + ((8 * a.D) * 2 + h) * 16);
+            lds_tile_wait(b);
+            const float c = lds_scalar(descale_lds + a.D) * pow2f(-t_cur);
             if (live) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < a.out_ch) a.out[pt * a.out_ch + row] = fmaf(o[r], c, b[r]);
+                    if (row < a.out_ch) a.out[pt * a.out_ch + row] = fmaf(o[r], c, b.q[r >> 2][r & 3]);
                 }
             }
         }
@@ -402,7 +469,7 @@ hipError_t launch_mlp_h2(const MlpLaunch& a, int mode, hipStream_t s) {
         if (n_cu[dev] <= 0) n_cu[dev] = 256;
     }
     const dim3 grid((unsigned)(tiles < n_cu[dev] ? tiles : n_cu[dev])), block(256);
-    const size_t lds = kBiasLdsBytes + kRingH * kChunkBytes;
+    const size_t lds = kRingH * kChunkBytes;   // + 20.5 KiB static (bias block, layer scales)
     static bool raised[64][3] = {};
     if (mode < 0 || mode > 2) return hipErrorInvalidValue;
     if (!raised[dev][mode]) {

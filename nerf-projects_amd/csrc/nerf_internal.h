@@ -59,6 +59,7 @@ struct PackedNet {
     float* d_descale = nullptr;
     int* d_chunk_layer = nullptr;
     float* d_chunk_max = nullptr;
+    float* d_gain = nullptr;     // per layer [max row sum of |W|, max |b|]: bounds a layer's outputs from its inputs
     int n_chunks = 0;
     int n_bias_tiles = 0;
     uint32_t skip_in_mask = 0;   // bit i: trunk layer i reads [input_pts, h]
@@ -71,6 +72,7 @@ struct MlpLaunch {
     const float* stream;
     const uint32_t* stream_h2;   // NERF_PRECISION_F16X2 only
     const float* descale;
+    const float* gain;
     const float* bias;
     int n_chunks;
     int n_bias_tiles;
@@ -106,6 +108,14 @@ std::vector<int> chunk_layers(const nerf_arch& arch, uint32_t skip_in_mask);
 // kernel launchers (mlp_kernel.hip, mlp_kernel_h2.hip, ray_kernels.hip)
 hipError_t launch_mlp(const MlpLaunch& a, int mode, hipStream_t s);
 hipError_t launch_mlp_h2(const MlpLaunch& a, int mode, hipStream_t s);
+// the Linear whose outputs are re-quantised after layer l (trunk 0..D-1, then feature_linear), for launch_layer_gains
+struct GainRefs {
+    int n;
+    unsigned long long w_off[kMaxDepth + 1], b_off[kMaxDepth + 1];
+    int out[kMaxDepth + 1], in[kMaxDepth + 1];
+};
+GainRefs gain_refs(const nerf_arch& arch, const std::vector<LinearDesc>& linears);
+hipError_t launch_layer_gains(const float* params, const GainRefs& refs, float* gain, hipStream_t s);
 hipError_t launch_convert_stream_h2(const float* stream, const int* chunk_layer, int n_chunks, float* chunk_max,
                                     uint32_t* out, float* descale, hipStream_t s);
 hipError_t launch_embed(const float* x, int64_t n, int multires, float* out, hipStream_t s);

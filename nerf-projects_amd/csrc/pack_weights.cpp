@@ -92,8 +92,8 @@ void row_tiles(std::vector<float>& out, const Linear& L, int row, int n_kt) {
 
 }  // namespace
 
-// Mirrors the chunk order pack_weights emits below: trunk layer i (its encoding chunks first when it reads
-// cat[input_pts, h]), then feature_linear (id D) and views_linears.0 (id D+1), or output_linear (id D).
+// Mirrors the chunk order pack_weights emits below: trunk layer i (hidden chunks, then its encoding chunks when it
+// reads cat[input_pts, h]), then feature_linear (id D) and views_linears.0 (id D+1), or output_linear (id D).
 std::vector<int> chunk_layers(const nerf_arch& a, uint32_t mask) {
     std::vector<int> ids;
     for (int i = 0; i < a.D; ++i) {
@@ -181,14 +181,16 @@ int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors,
         const int in = (i == 0) ? a.input_ch : (pe_in ? a.W + a.input_ch : a.W);
         Linear L{tensors[2 * i], tensors[2 * i + 1], a.W, in};
         bias_tiles(bias, L, 8);
-        if (pe_in) {
-            chunk_ktile(st, L, 8, xyz_col(0));
-            chunk_ktile(st, L, 8, xyz_col(1));
-        }
         if (i > 0) {
             const int off = pe_in ? a.input_ch : 0;
             for (int kt = 0; kt < 8; ++kt)
                 chunk_ktile(st, L, 8, [kt, off](int t, int h) { return off + hidden_col(kt, t, h); });
+        }
+        // the encoding chunks of a skip layer FOLLOW its hidden chunks: the fp16-pair kernel converts the previous
+        // layer's outputs tile by tile while the hidden chunks run and has nothing left to hide behind these two
+        if (pe_in) {
+            chunk_ktile(st, L, 8, xyz_col(0));
+            chunk_ktile(st, L, 8, xyz_col(1));
         }
     }
     // views_linears.0 is tensors[2D], [2D+1] in both variants (nerf/nerf.py:43 builds it always)
