@@ -95,17 +95,6 @@ __device__ __forceinline__ void mma_range(f32x16& acc, const Frag16& f, const f3
     for (int k = LO; k < HI; ++k) acc = mfma(f.q[k >> 2][k & 3], b[k], acc);
 }
 
-// One wave per SIMD has nobody to hide LDS latency behind, so fragment reads are software-
-// pipelined by hand: the reads of step n+1 are issued right after the FIRST MFMA of step n (so
-// the s_waitcnt hipcc inserts for that MFMA only waits for reads issued a whole step earlier),
-// and the other 15 MFMAs (960 matrix-pipe cycles) cover their latency.
-#define SCHED_STEP()                                          \
-    do {                                                      \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);    \
-        __builtin_amdgcn_sched_group_barrier(0x008, 15, 0);   \
-    } while (0)
-
 template <int S>
 struct StepTag {
     static constexpr int value = S;
@@ -124,12 +113,18 @@ struct Range {
 template <int S, int NSTEP, class Body>
 __device__ __forceinline__ void run_steps(Pipe& p, Frag16& cur, const f32x4* fr, const f32x4* fr_next, Body& body) {
     if constexpr (S < NSTEP) {
+        // order pinned with scheduling fences: the step's first MFMA, the four fragment reads of step S+1 into the
+        // other half of a double buffer, then the other 15 MFMAs (960 matrix-pipe cycles for the reads to return).
+        // Left to itself hipcc sinks the reads below the step's last MFMA to share registers and waits for them.
+        body(StepTag<S>{}, Range<0, 1>{}, cur);
+        __builtin_amdgcn_sched_barrier(0);
         Frag16 nxt = (S + 1 < NSTEP) ? read_frags(fr, (S + 1) * 4) : read_frags(fr_next, 0);
-        body(StepTag<S>{}, Range<0, 16>{}, cur);
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (S == NSTEP / 2) {
             // the step after the barrier also issues the 8 LDS-DMA pieces of chunk c+2, one per MFMA
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            const int nx = p.c + 2 < p.n ? p.c + 2 : p.c + 2 - p.n;   // wraps into the next tile's stream
+            prefetch_chunk(p, nx, ring_next(p.b, 2));
+            body(StepTag<S>{}, Range<1, 16>{}, cur);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -137,18 +132,15 @@ __device__ __forceinline__ void run_steps(Pipe& p, Frag16& cur, const f32x4* fr,
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
         } else {
-            SCHED_STEP();
+            body(StepTag<S>{}, Range<1, 16>{}, cur);
         }
+        __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
         if constexpr (S == NSTEP / 2 - 1) {
-            // keep the step's 15 trailing MFMAs above the barrier: the reads issued before them have
-            // returned by then, so the counters the barrier drains (vmcnt, lgkmcnt) are already empty
-            __builtin_amdgcn_sched_barrier(0);
 #ifndef NERF_ABLATE_BARRIER
             __syncthreads();
 #endif
-            const int nx = p.c + 2 < p.n ? p.c + 2 : p.c + 2 - p.n;   // wraps into the next tile's stream
-            prefetch_chunk(p, nx, ring_next(p.b, 2));   // scheduled among the next step's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
         }
         run_steps<S + 1, NSTEP>(p, cur, fr, fr_next, body);
     }
@@ -286,7 +278,14 @@ void nerf_mlp_kernel(const MlpLaunch a) {
             chunk_ktile8(pipe, cur, acc, x0);
             chunk_ktile8(pipe, cur, acc, x1);
         }
-        if (is_feature) activate<8, false>(hid, acc); else activate<8, true>(hid, acc);
+        if (is_feature) {
+            // the stream carries alpha_linear as an MFMA tile here for the fp16-pair kernel; this kernel has it from
+            // row_dot above and only keeps the ring turning
+            consume_chunk<8>(pipe, cur, [&](auto, auto, const Frag16&) {});
+            activate<8, false>(hid, acc);
+        } else {
+            activate<8, true>(hid, acc);
+        }
     }
 
     const bool live = pt_raw < a.n_points;

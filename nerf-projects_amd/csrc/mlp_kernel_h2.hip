@@ -41,12 +41,13 @@ __device__ __forceinline__ f32x16 mma(const f32x4& a, const u32x4& b, f32x16 c) 
 }
 
 // ---- weight-stream pipeline ------------------------------------------------------------
-// Four 32 KiB LDS buffers form a ring: while chunk c is consumed (48 MFMAs, ~1500 cycles), chunk c+1
-// is resident and chunks c+2, c+3 are in flight, so a load has two chunk periods to land. One barrier
-// per chunk, mid-chunk:
-//   vmcnt(8)  -> this wave's share of chunk c+1 has landed (only chunk c+2's 8 loads may be pending)
-//   s_barrier -> every wave's share has, and every wave has finished chunk c-1
-//   then issue chunk c+3 into the buffer chunk c-1 occupied.
+// Four 32 KiB LDS buffers form a ring: while chunk c is consumed (48 MFMAs, ~1500 cycles), chunk c+1 is resident,
+// chunk c+2 half issued and chunk c+3 about to be. A chunk travels as 8 LDS-DMA pieces per wave (1 KiB each), and
+// the pieces are spread over the steps instead of issued in a burst (a burst of 32 KiB of LDS writes stalls the
+// fragment reads of all four waves): the first-half steps of chunk c issue pieces 4..7 of chunk c+2, the
+// second-half steps pieces 0..3 of chunk c+3. One barrier per chunk, mid-chunk:
+//   vmcnt(8)  -> this wave's share of chunk c+1 has landed (only chunk c+2's 8 pieces may be pending)
+//   s_barrier -> every wave's share has, and every wave has finished chunk c-1, whose buffer chunk c+3 takes.
 constexpr int kRingH = 4;
 
 struct PipeH {
@@ -60,12 +61,18 @@ __device__ __forceinline__ int ringh_next(int b, int k) {
     return b >= kRingH ? b - kRingH : b;
 }
 
-__device__ __forceinline__ void prefetch_chunk(const PipeH& p, int chunk, int slot) {
-    const char* g = p.stream + (size_t)chunk * kChunkBytes + p.wave * 8192 + p.lane * 16;
-    char* l = p.lds + slot * kChunkBytes + p.wave * 8192;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        __builtin_amdgcn_global_load_lds(GLB_PTR(g + i * 1024), LDS_PTR(l + i * 1024), 16, 0, 0);
+template <int I>
+__device__ __forceinline__ void prefetch_piece(const PipeH& p, int chunk, int slot) {
+    const char* g = p.stream + (size_t)chunk * kChunkBytes + p.wave * 8192 + p.lane * 16 + I * 1024;
+    char* l = p.lds + slot * kChunkBytes + p.wave * 8192 + I * 1024;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(l), 16, 0, 0);
+}
+template <int LO, int HI>
+__device__ __forceinline__ void prefetch_pieces(const PipeH& p, int chunk, int slot) {
+    if constexpr (LO < HI) {
+        prefetch_piece<LO>(p, chunk, slot);
+        prefetch_pieces<LO + 1, HI>(p, chunk, slot);
+    }
 }
 
 __device__ __forceinline__ const f32x4* ring_frags(const PipeH& p, int slot) {
@@ -83,11 +90,17 @@ __device__ __forceinline__ Frag4 read_frags(const f32x4* fr, int group) {
     return f;
 }
 
-// the six products of one step, small terms first; PART 0 = the first product, PART 1 = the other five
-template <int PART>
+// the six products of one step, small terms first; PART 0 = the first product, PART 1 = the other five.
+// FIRST: the accumulator tile starts from zero (an inline-constant C operand instead of 16 register writes).
+template <int PART, bool FIRST>
 __device__ __forceinline__ void mma_step(f32x16& acc, const Frag4& f, const XT& x) {
     if constexpr (PART == 0) {
-        acc = mma(f.q[1], x.hi[0], acc);
+        if constexpr (FIRST) {
+            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            acc = mma(f.q[1], x.hi[0], zero);
+        } else {
+            acc = mma(f.q[1], x.hi[0], acc);
+        }
     } else {
 #ifndef NERF_ABLATE_MFMA
         acc = mma(f.q[0], x.lo[0], acc);
@@ -112,79 +125,63 @@ struct PartTag {
 
 // Consume the current chunk in NSTEP steps of 6 MFMAs; `cur` holds the fragments of step 0 on entry and
 // of the NEXT chunk's step 0 on exit. One wave per SIMD has nobody to hide LDS latency behind, so the order
-// is pinned with scheduling fences: first MFMA of step n, the four fragment reads of step n+1 (into the
-// other half of a double buffer), the other five MFMAs (160 matrix-pipe cycles for the reads to return).
-// Left to itself hipcc sinks the reads below the step's last MFMA to share registers and waits for them.
-template <int S, int NSTEP, class Body>
+// is pinned with scheduling fences: first MFMA of step n (body part 0); the small reads the body wants for the
+// NEXT step (part 2), the four fragment reads of step n+1 into the other half of a double buffer and this step's
+// LDS-DMA pieces; then the other five MFMAs with the body's vector work spread between them (part 1): 160
+// matrix-pipe cycles for the fragment reads to return. Left to itself hipcc sinks the reads below the step's last
+// MFMA to share registers and waits for them.
+template <int S, int NSTEP, int VALU_PER_MFMA, class Body>
 __device__ __forceinline__ void run_steps(PipeH& p, Frag4& cur, const f32x4* fr, const f32x4* fr_next, Body& body) {
     if constexpr (S < NSTEP) {
         body(StepTag<S>{}, PartTag<0>{}, cur);
         __builtin_amdgcn_sched_barrier(0);
+        body(StepTag<S>{}, PartTag<2>{}, cur);   // before the fragment reads: lds_pair_wait counts on that
         Frag4 nxt = (S + 1 < NSTEP) ? read_frags(fr, (S + 1) * 4) : read_frags(fr_next, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (S == NSTEP / 2) {
-            // the step after the barrier also issues the 8 LDS-DMA pieces of chunk c+3, two per MFMA
-            const int nx = p.c + 3 < p.n ? p.c + 3 : p.c + 3 - p.n;   // wraps into the next tile's stream
 #ifndef NERF_ABLATE_DMA
-            prefetch_chunk(p, nx, ringh_next(p.b, 3));
+        constexpr int per = 8 / NSTEP;   // pieces per step
+        if constexpr (S < NSTEP / 2) {
+            const int nx = p.c + 2 < p.n ? p.c + 2 : p.c + 2 - p.n;   // wraps into the next tile's stream
+            prefetch_pieces<4 + S * per, 4 + (S + 1) * per>(p, nx, ringh_next(p.b, 2));
+        } else {
+            const int nx = p.c + 3 < p.n ? p.c + 3 : p.c + 3 - p.n;
+            prefetch_pieces<(S - NSTEP / 2) * per, (S - NSTEP / 2 + 1) * per>(p, nx, ringh_next(p.b, 3));
+        }
 #endif
-            body(StepTag<S>{}, PartTag<1>{}, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        body(StepTag<S>{}, PartTag<1>{}, cur);
+        if constexpr (VALU_PER_MFMA > 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        } else {
-            body(StepTag<S>{}, PartTag<1>{}, cur);
         }
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
         if constexpr (S == NSTEP / 2 - 1) {
+#ifdef NERF_ABLATE_BARRIER
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#else
             asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
-        run_steps<S + 1, NSTEP>(p, cur, fr, fr_next, body);
+        run_steps<S + 1, NSTEP, VALU_PER_MFMA>(p, cur, fr, fr_next, body);
     }
 }
 
-template <int NSTEP, class Body>
+template <int NSTEP, int VALU_PER_MFMA, class Body>
 __device__ __forceinline__ void consume_chunk(PipeH& p, Frag4& cur, Body body) {
     const f32x4* fr = ring_frags(p, p.b);
     const f32x4* fr_next = ring_frags(p, ringh_next(p.b, 1));
-    run_steps<0, NSTEP>(p, cur, fr, fr_next, body);
+    run_steps<0, NSTEP, VALU_PER_MFMA>(p, cur, fr, fr_next, body);
     ++p.c;
     p.b = ringh_next(p.b, 1);
 }
 
-// chunk kinds: the group order is the fp32 stream's (pack_weights.cpp) with each unit of four groups
-// re-cut into [k-slice][hi|lo] by convert_stream_h2 below
-__device__ __forceinline__ void chunk_ktile8(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x) {
-    consume_chunk<8>(p, cur, [&](auto tag, auto part, const Frag4& f) {
-        mma_step<decltype(part)::value>(acc[decltype(tag)::value], f, x);
-    });
-}
-__device__ __forceinline__ void chunk_ktile4(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x) {
-    consume_chunk<4>(p, cur, [&](auto tag, auto part, const Frag4& f) {
-        mma_step<decltype(part)::value>(acc[decltype(tag)::value], f, x);
-    });
-}
-__device__ __forceinline__ void chunk_pair4(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x0, const XT& x1) {
-    consume_chunk<8>(p, cur, [&](auto tag, auto part, const Frag4& f) {
-        constexpr int s = decltype(tag)::value;
-        mma_step<decltype(part)::value>(acc[s & 3], f, s < 4 ? x0 : x1);
-    });
-}
-template <int NKT>
-__device__ __forceinline__ void chunk_row(PipeH& p, Frag4& cur, f32x16& acc, const XT (&x)[8]) {
-    consume_chunk<NKT>(p, cur, [&](auto tag, auto part, const Frag4& f) {
-        mma_step<decltype(part)::value>(acc, f, x[decltype(tag)::value]);
-    });
-}
-
 // ---- per-point scaling and the fp16 split --------------------------------------------------------
-// exponent t such that max * 2^t lies in [2^9, 2^10): headroom of 64 below the fp16 maximum, and the low
-// piece of anything within 2^-13 of the point's largest activation is a normal fp16 number
+// exponent t such that max * 2^t lies in [2^9, 2^10): headroom of 64 below the fp16 maximum
 __device__ __forceinline__ int pick_exponent(float m) {
     const int t = 10 - __builtin_amdgcn_frexp_expf(m);   // frexp_exp(0) = 0
     return t < -60 ? -60 : (t > 60 ? 60 : t);   // keeps descale * 2^-t finite
@@ -206,27 +203,29 @@ __device__ __forceinline__ h16x2 round_pair(float a, float b) {
     return __builtin_convertvector(v, h16x2);
 }
 
-// v * sc -> (hi, lo) for the 16 registers of one tile
-__device__ __forceinline__ void split_tile(XT& out, const f32x16& v, float sc) {
-#ifdef NERF_ABLATE_SPLIT
-    out.hi[0][0] = __float_as_uint(v[0] * sc);
-    return;
-#endif
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float a = v[8 * s + 2 * q] * sc, b = v[8 * s + 2 * q + 1] * sc;
-            const h16x2 hi = round_pair(a, b);
-            const h16x2 lo = round_pair(a - (float)hi[0], b - (float)hi[1]);
-            out.hi[s][q] = __builtin_bit_cast(unsigned, hi);
-            out.lo[s][q] = __builtin_bit_cast(unsigned, lo);
-        }
+// registers 2P, 2P+1 of a tile (already scaled) -> packed (hi, lo)
+template <int P>
+__device__ __forceinline__ void split_pair(XT& out, float a, float b) {
+    const h16x2 hi = round_pair(a, b);
+    // fma(hi, -1, v): the exact remainder, rounded once to fp16 (v_fma_mixlo/mixhi_f16 where hipcc sees the pattern)
+    const h16x2 lo = {(_Float16)__builtin_fmaf((float)hi[0], -1.0f, a), (_Float16)__builtin_fmaf((float)hi[1], -1.0f, b)};
+    out.hi[P >> 2][P & 3] = __builtin_bit_cast(unsigned, hi);
+    out.lo[P >> 2][P & 3] = __builtin_bit_cast(unsigned, lo);
 }
 
-// multiply a split tile by 2^d (exact while nothing leaves the fp16 range; d <= 0 by construction)
+template <int P>
+__device__ __forceinline__ void split_pairs(XT& out, const f32x16& v, float sc) {
+    if constexpr (P < 8) {
+        split_pair<P>(out, v[2 * P] * sc, v[2 * P + 1] * sc);
+        split_pairs<P + 1>(out, v, sc);
+    }
+}
+// v * sc -> (hi, lo) for the 16 registers of one tile
+__device__ __forceinline__ void split_tile(XT& out, const f32x16& v, float sc) { split_pairs<0>(out, v, sc); }
+
+// multiply a split tile by 2^d (exact while nothing leaves the fp16 range)
 __device__ __forceinline__ void rescale_tile(XT& x, int d) {
-    const _Float16 f = (_Float16)pow2f(d < -30 ? -30 : d);
+    const _Float16 f = (_Float16)pow2f(d < -30 ? -30 : (d > 15 ? 15 : d));
     const h16x2 ff = {f, f};
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -240,16 +239,19 @@ __device__ __forceinline__ void rescale_tile(XT& x, int d) {
         }
 }
 
-// 64 bytes of the bias block per lane. hipcc guards every LDS load it can see with s_waitcnt vmcnt(0) while an
-// LDS-DMA write is in flight (it cannot tell the bias block from the ring), which would drain the weight pipeline
-// twice per layer; these reads are therefore issued from inline asm, with their own lgkmcnt wait (LDS returns in
-// order, and the waits hipcc computes for its own reads can only become stricter by the extra entries).
+// ---- LDS reads outside hipcc's LDS-DMA guard ---------------------------------------------------------------
+// hipcc guards every LDS load it can see with s_waitcnt vmcnt(0) while an LDS-DMA write is in flight (it cannot
+// tell the bias block from the ring), which would drain the weight pipeline at every bias read; these reads are
+// issued from inline asm with their own lgkmcnt wait (LDS returns in order, and the waits hipcc computes for its
+// own reads can only become stricter by the extra entries).
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+}
 struct Tile16 {
     f32x4 q[4];
 };
-__device__ __forceinline__ Tile16 lds_tile_issue(const float* p) {
+__device__ __forceinline__ Tile16 lds_tile_issue(unsigned addr) {
     Tile16 t;
-    const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
     asm volatile(
         "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
         "ds_read_b128 %3, %4 offset:48"
@@ -263,53 +265,161 @@ __device__ __forceinline__ void lds_tile_wait(Tile16& t) {
 }
 __device__ __forceinline__ float lds_scalar(const float* p) {
     float v;
-    const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds_addr(p)) : "memory");
     return v;
 }
+// the two bias entries of one register pair, `OFF` bytes past `addr`; issued one step ahead of their use
+template <int OFF>
+__device__ __forceinline__ f32x2 lds_pair_issue(unsigned addr) {
+    f32x2 r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+// valid when at least NEWER LDS reads were issued after the pair's (run_steps issues four fragment reads per step)
+template <int NEWER>
+__device__ __forceinline__ void lds_pair_wait(f32x2& r) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(NEWER) : "memory");
+}
 
-// y = acc * c + bias (and ReLU above `floor`); returns this lane's largest |y|
-template <int N>
-__device__ __forceinline__ float finish_layer(f32x16 (&y)[8], const f32x16 (&acc)[8], const float* bias_lds, int tile,
-                                              int h, float c, float floor) {
-    float m0 = 0.0f, m1 = 0.0f;
-    Tile16 nxt = lds_tile_issue(bias_lds + (tile * 2 + h) * 16);
+// ---- the layer whose raw sums wait to become the next layer's operands -------------------------------------
+// A layer's 8 accumulator tiles are not converted when the layer ends but one tile per chunk of the NEXT layer
+// (which accumulates into the other accumulator set), one register pair per MFMA step, in the shadow of the
+// MFMAs. That needs the output scale before the outputs exist: it is chosen from the bound
+//   |y_j| <= max_j sum_k |W_jk| * max_k |x_k| + max_j |b_j|      (gain table, launch_layer_gains)
+// which is loose by 2^4..2^5 on NeRF weights; the split tolerates 2^11 (the low halves of values more than 2^-2
+// below the scaled maximum go subnormal with absolute error 2^-25, i.e. 2^-35 of the 2^10 the bound maps to).
+struct Pending {
+    float c;       // raw sum -> activation: descale * 2^-t_in (per point)
+    float floor;   // 0 for ReLU, -inf for feature_linear
+    float sc;      // activation -> operand: 2^t_out (per point)
+    int t_out;
+    unsigned bias_addr;    // LDS address of this half-wave's bias entries of tile 0 (tile t: + 128 t)
+    float m;       // running max |y|
+};
+
+template <int P>
+__device__ __forceinline__ void convert_pair(XT& dst, const f32x16& src, Pending& pd, const f32x2& b) {
+#ifdef NERF_ABLATE_CONV
+    if (P == 0) dst.hi[0][0] = __float_as_uint(src[0] + b[0]);
+    return;
+#endif
+    const float y0 = fmaxf(fmaf(src[2 * P], pd.c, b[0]), pd.floor);
+    const float y1 = fmaxf(fmaf(src[2 * P + 1], pd.c, b[1]), pd.floor);
+    pd.m = fmaxf(fmaxf(pd.m, fabsf(y0)), fabsf(y1));
+    const float a0 = y0 * pd.sc, a1 = y1 * pd.sc;
+    const unsigned hi = __builtin_bit_cast(unsigned, round_pair(a0, a1));
+    // lo = rn16(a - hi): one fma with an fp16 source and an fp16 result per half (hipcc does not form these itself)
+    unsigned lo;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(a1));
+    dst.hi[P >> 2][P & 3] = hi;
+    dst.lo[P >> 2][P & 3] = lo;
+}
+
+// a whole tile at once (not hidden: tile 0 at the start of a layer)
+template <int P>
+__device__ __forceinline__ void convert_pairs(XT& dst, const f32x16& src, Pending& pd, const Tile16& b) {
+    if constexpr (P < 8) {
+        convert_pair<P>(dst, src, pd, f32x2{b.q[P >> 1][2 * (P & 1)], b.q[P >> 1][2 * (P & 1) + 1]});
+        convert_pairs<P + 1>(dst, src, pd, b);
+    }
+}
+template <int T>
+__device__ __forceinline__ void convert_tile(XT& dst, const f32x16& src, Pending& pd) {
+    Tile16 b = lds_tile_issue(pd.bias_addr + 128 * T);
+    lds_tile_wait(b);
+    convert_pairs<0>(dst, src, pd, b);
+}
+
+// chunk kinds (group order: pack_weights.cpp, each unit of four groups re-cut into [k-slice][hi|lo] by
+// convert_stream_h2 below). CONV >= 0: while the chunk runs, step s converts register pair s of pending tile CONV;
+// its two bias entries are requested one step earlier.
+template <int CONV, bool FIRST>
+__device__ __forceinline__ void chunk_ktile8(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x, XT (&hid)[8],
+                                             const f32x16 (&pend)[8], Pending& pd) {
+    f32x2 r[2];
+    if constexpr (CONV >= 0) r[0] = lds_pair_issue<128 * (CONV < 0 ? 0 : CONV)>(pd.bias_addr);
+    consume_chunk<8, (CONV >= 0 ? 3 : 0)>(p, cur, [&](auto tag, auto part, const Frag4& f) {
+        constexpr int s = decltype(tag)::value, pt = decltype(part)::value;
+        if constexpr (pt == 2) {
+            if constexpr (CONV >= 0 && s < 7) r[(s + 1) & 1] = lds_pair_issue<128 * (CONV < 0 ? 0 : CONV) + 8 * (s + 1)>(pd.bias_addr);
+        } else {
+            mma_step<pt, FIRST>(acc[s], f, x);
+            if constexpr (pt == 1 && CONV >= 0) {
+                lds_pair_wait<5>(r[s & 1]);
+                convert_pair<s>(hid[CONV < 0 ? 0 : CONV], pend[CONV < 0 ? 0 : CONV], pd, r[s & 1]);
+            }
+        }
+    });
+}
+// one k-tile against 4 output tiles (direction part of the view layer)
+__device__ __forceinline__ void chunk_ktile4(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x) {
+    consume_chunk<4, 0>(p, cur, [&](auto tag, auto part, const Frag4& f) {
+        if constexpr (decltype(part)::value != 2) mma_step<decltype(part)::value, false>(acc[decltype(tag)::value], f, x);
+    });
+}
+// two k-tiles against 4 output tiles (feature part of the view layer): steps 0-3 use x0, 4-7 use x1; converts
+// pending tiles CONV and CONV + 1 meanwhile (two register pairs per step)
+template <int CONV, bool FIRST>
+__device__ __forceinline__ void chunk_pair4(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x0, const XT& x1,
+                                            XT (&hid)[8], const f32x16 (&pend)[8], Pending& pd) {
+    constexpr int C0 = CONV < 0 ? 0 : CONV;
+    f32x2 r0[2], r1[2];
+    if constexpr (CONV >= 0) {
+        r0[0] = lds_pair_issue<128 * C0>(pd.bias_addr);
+        r1[0] = lds_pair_issue<128 * (C0 + 1)>(pd.bias_addr);
+    }
+    consume_chunk<8, (CONV >= 0 ? 6 : 0)>(p, cur, [&](auto tag, auto part, const Frag4& f) {
+        constexpr int s = decltype(tag)::value, pt = decltype(part)::value;
+        if constexpr (pt == 2) {
+            if constexpr (CONV >= 0 && s < 7) {
+                r0[(s + 1) & 1] = lds_pair_issue<128 * C0 + 8 * (s + 1)>(pd.bias_addr);
+                r1[(s + 1) & 1] = lds_pair_issue<128 * (C0 + 1) + 8 * (s + 1)>(pd.bias_addr);
+            }
+        } else {
+            if constexpr (s < 4) mma_step<pt, FIRST>(acc[s & 3], f, x0);
+            else mma_step<pt, false>(acc[s & 3], f, x1);
+            if constexpr (pt == 1 && CONV >= 0) {
+                lds_pair_wait<6>(r1[s & 1]);
+                convert_pair<s>(hid[C0], pend[C0], pd, r0[s & 1]);
+                convert_pair<s>(hid[C0 + 1], pend[C0 + 1], pd, r1[s & 1]);
+            }
+        }
+    });
+}
+// 8 k-tiles against ONE output tile: step s = k-tile s
+__device__ __forceinline__ void chunk_row8(PipeH& p, Frag4& cur, f32x16& acc, const XT (&x)[8]) {
+    consume_chunk<8, 0>(p, cur, [&](auto tag, auto part, const Frag4& f) {
+        constexpr int s = decltype(tag)::value, pt = decltype(part)::value;
+        if constexpr (pt != 2) {
+            if constexpr (s == 0) mma_step<pt, true>(acc, f, x[0]);
+            else mma_step<pt, false>(acc, f, x[s]);
+        }
+    });
+}
+
+// y = relu(acc * c + bias) for the view layer's 4 tiles (the last layer: nothing to overlap with)
+__device__ __forceinline__ void finish_views(f32x16 (&y)[4], const f32x16 (&acc)[8], unsigned bias_addr, float c) {
+    Tile16 nxt = lds_tile_issue(bias_addr);
 #pragma unroll
-    for (int t = 0; t < N; ++t) {
+    for (int t = 0; t < 4; ++t) {
         Tile16 b = nxt;
         lds_tile_wait(b);
-        if (t + 1 < N) nxt = lds_tile_issue(bias_lds + ((tile + t + 1) * 2 + h) * 16);
+        if (t + 1 < 4) nxt = lds_tile_issue(bias_addr + 128 * (t + 1));
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const float v0 = fmaxf(fmaf(acc[t][r], c, b.q[r >> 2][r & 3]), floor);
-            const float v1 = fmaxf(fmaf(acc[t][r + 1], c, b.q[(r + 1) >> 2][(r + 1) & 3]), floor);
-            y[t][r] = v0;
-            y[t][r + 1] = v1;
-            m0 = fmaxf(m0, fabsf(v0));
-            m1 = fmaxf(m1, fabsf(v1));
-        }
+        for (int r = 0; r < 16; ++r) y[t][r] = fmaxf(fmaf(acc[t][r], c, b.q[r >> 2][r & 3]), 0.0f);
     }
-    return fmaxf(m0, m1);
 }
 
-template <int N>
-__device__ __forceinline__ void zero_tiles(f32x16 (&acc)[8]) {
-#pragma unroll
-    for (int t = 0; t < N; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-}
-
-// One output row of a Linear over NKT fp32 activation tiles (weights per register in the bias block)
-template <int NKT>
-__device__ __forceinline__ float row_dot(const f32x16 (&x)[8], const float* bias_lds, int tile, int h) {
+// One output row of a Linear over 4 fp32 activation tiles (weights per register in the bias block)
+__device__ __forceinline__ float row_dot4(const f32x16 (&x)[4], unsigned w_addr) {
     float s0 = 0.0f, s1 = 0.0f;
-    Tile16 nxt = lds_tile_issue(bias_lds + (tile * 2 + h) * 16);
+    Tile16 nxt = lds_tile_issue(w_addr);
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+    for (int kt = 0; kt < 4; ++kt) {
         Tile16 w = nxt;
         lds_tile_wait(w);
-        if (kt + 1 < NKT) nxt = lds_tile_issue(bias_lds + ((tile + kt + 1) * 2 + h) * 16);
+        if (kt + 1 < 4) nxt = lds_tile_issue(w_addr + 128 * (kt + 1));
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             s0 = fmaf(w.q[r >> 2][r & 3], x[kt][r], s0);
@@ -324,25 +434,27 @@ __device__ __forceinline__ float row_dot(const f32x16 (&x)[8], const float* bias
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void nerf_mlp_h2_kernel(const MlpLaunch a) {
-    // The ring is the dynamic LDS allocation, the bias block a separate static one: hipcc guards every LDS read that
-    // may alias an in-flight LDS-DMA write with s_waitcnt vmcnt(0), which would drain the weight pipeline at each
-    // bias read; two distinct LDS objects cannot alias.
+    // The ring is the dynamic LDS allocation; the bias block and the small per-layer tables are static.
     extern __shared__ __attribute__((aligned(16))) char ring_lds[];
     __shared__ __attribute__((aligned(16))) float bias_lds[kBiasLdsBytes / 4];
-    __shared__ float descale_lds[kMaxDepth + 2];
+    __shared__ float descale_lds[kMaxDepth + 3];
+    __shared__ float gain_lds[2 * (kMaxDepth + 2)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
 
     PipeH pipe{(const char*)a.stream_h2, ring_lds, 0, 0, a.n_chunks, wave, lane};
-    prefetch_chunk(pipe, 0, 0);
-    prefetch_chunk(pipe, 1, 1);
-    prefetch_chunk(pipe, 2, 2);
+    prefetch_pieces<0, 8>(pipe, 0, 0);
+    prefetch_pieces<0, 8>(pipe, 1, 1);
+    prefetch_pieces<0, 4>(pipe, 2, 2);   // chunk 0's first-half steps issue the other four
     for (int i = threadIdx.x; i < a.n_bias_tiles * kBiasTileFloats; i += 256) bias_lds[i] = a.bias[i];
-    if (threadIdx.x < a.D + 2) descale_lds[threadIdx.x] = a.descale[threadIdx.x];
-    __syncthreads();   // chunks 0..2, the bias block and the layer scales are in LDS
+    if (threadIdx.x < a.D + 3) descale_lds[threadIdx.x] = a.descale[threadIdx.x];
+    if (threadIdx.x < 2 * (a.D + 1)) gain_lds[threadIdx.x] = a.gain[threadIdx.x];
+    __syncthreads();   // chunks 0, 1, the bias block and the layer tables are in LDS
     Frag4 cur = read_frags(ring_frags(pipe, 0), 0);
 
+    const unsigned bias0 = lds_addr(bias_lds) + 64 * h;   // this half-wave's entries of bias-block tile 0
+    const int n_layers = a.use_viewdirs ? a.D + 1 : a.D;
     const int64_t n_tiles = (a.n_points + kPointsPerGroup - 1) / kPointsPerGroup;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         pipe.c = 0;
@@ -350,98 +462,140 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
         const int64_t pt_raw = tile0 + (lane & 31);
         const int64_t pt = pt_raw < a.n_points ? pt_raw : a.n_points - 1;
 
-        XT xp0, xp1, xd;
+        XT xp0, xp1;
         float m_pe, m_dd;
-        int t_pe, t_dd;
+        int t_pe;
         {
             f32x16 x0, x1, dd;
             load_inputs<MODE>(a, pt, h, x0, x1, dd);
             m_pe = half_max(tile_absmax(x1, tile_absmax(x0, 0.0f)));
             m_dd = half_max(tile_absmax(dd, 0.0f));
             t_pe = pick_exponent(m_pe);
-            t_dd = pick_exponent(m_dd);
-            const float spe = pow2f(t_pe), sdd = pow2f(t_dd);
-            split_tile(xp0, x0, spe);
-            split_tile(xp1, x1, spe);
-            split_tile(xd, dd, sdd);
+            split_tile(xp0, x0, pow2f(t_pe));
+            split_tile(xp1, x1, pow2f(t_pe));   // gamma(dir) is re-derived at the view layer: 16 registers for 9 layers
         }
 
         XT hid[8];
-        f32x16 acc[8], y[8];
-        int t_cur;
+        f32x16 accA[8], accB[8];
+        Pending pd;
         float sigma = 0.0f;
+        float m_prev;    // largest |activation| of the layer before the pending one... of its inputs
+
+        // what the raw sums of layer l become: called when its chunks are done. m_in = largest |input| of layer l
+        // (true units), t_in = exponent its inputs were scaled by
+        auto make_pending = [&](int l, float m_in, int t_in) {
+            const bool is_feature = a.use_viewdirs && l == a.D;
+            pd.c = lds_scalar(descale_lds + l) * pow2f(-t_in);
+            pd.floor = is_feature ? -__builtin_inff() : 0.0f;
+            float bound = fmaf(lds_scalar(gain_lds + 2 * l), m_in, lds_scalar(gain_lds + 2 * l + 1)) * 1.001f;
+            // the next layer may concatenate these outputs with inputs that must fit the same scale
+            if (is_feature) bound = fmaxf(bound, m_dd);
+            else if ((a.skip_in_mask >> (l + 1)) & 1) bound = fmaxf(bound, m_pe);
+            pd.t_out = pick_exponent(bound);
+            pd.sc = pow2f(pd.t_out);
+            pd.bias_addr = bias0 + 128 * (is_feature ? 8 * a.D + 1 : 8 * l);
+            pd.m = 0.0f;
+        };
+        // all 8 tiles of the pending layer are converted: its true output range
+        auto close_pending = [&]() { m_prev = half_max(pd.m); };
 
         // layer 0: gamma(xyz) -> W (nerf.py:70-73)
-        zero_tiles<8>(acc);
-        chunk_ktile8(pipe, cur, acc, xp0);
-        chunk_ktile8(pipe, cur, acc, xp1);
-        {
-            float m = half_max(finish_layer<8>(y, acc, bias_lds, 0, h, lds_scalar(descale_lds) * pow2f(-t_pe), 0.0f));
-            if (a.D == 1 && a.use_viewdirs) sigma = row_dot<8>(y, bias_lds, 8 * a.D + 14, h) + lds_scalar(bias_lds + (8 * a.D) * 32);
-            if ((a.skip_in_mask >> 1) & 1) m = fmaxf(m, m_pe);
-            t_cur = pick_exponent(m);
-            const float sc = pow2f(t_cur);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) split_tile(hid[t], y[t], sc);
-        }
+        chunk_ktile8<-1, true>(pipe, cur, accA, xp0, hid, accB, pd);
+        chunk_ktile8<-1, false>(pipe, cur, accA, xp1, hid, accB, pd);
+        make_pending(0, m_pe, t_pe);
 
-        // trunk layers 1..D-1, then (with viewdirs) feature_linear as layer D without ReLU
-        const int n_layers = a.use_viewdirs ? a.D + 1 : a.D;
-        for (int i = 1; i < n_layers; ++i) {
-            const bool is_feature = (i == a.D);
-            const float c = lds_scalar(descale_lds + i) * pow2f(-t_cur);
-            zero_tiles<8>(acc);
-            if (!is_feature && ((a.skip_in_mask >> i) & 1)) {
+        // trunk layers 1..D-1, then (with viewdirs) feature_linear as layer D without ReLU. Layer l accumulates
+        // into `out` while the pending layer l-1 is converted out of `pend`.
+        auto layer_pass = [&](f32x16 (&pend)[8], f32x16 (&out)[8], int l) {
+            convert_tile<0>(hid[0], pend[0], pd);
+            chunk_ktile8<1, true>(pipe, cur, out, hid[0], hid, pend, pd);
+            chunk_ktile8<2, false>(pipe, cur, out, hid[1], hid, pend, pd);
+            chunk_ktile8<3, false>(pipe, cur, out, hid[2], hid, pend, pd);
+            chunk_ktile8<4, false>(pipe, cur, out, hid[3], hid, pend, pd);
+            chunk_ktile8<5, false>(pipe, cur, out, hid[4], hid, pend, pd);
+            chunk_ktile8<6, false>(pipe, cur, out, hid[5], hid, pend, pd);
+            chunk_ktile8<7, false>(pipe, cur, out, hid[6], hid, pend, pd);
+            chunk_ktile8<-1, false>(pipe, cur, out, hid[7], hid, pend, pd);
+            close_pending();
+            const int t_in = pd.t_out;
+            float m_in = m_prev;
+            if (a.use_viewdirs && l == a.D) {
+                // alpha_linear reads the post-ReLU trunk output (nerf.py:86), i.e. this layer's input: one more
+                // chunk, a single-row tile accumulated into a pending tile that is no longer needed
+                chunk_row8(pipe, cur, pend[0], hid);
+                sigma = fmaf(pend[0][0], lds_scalar(descale_lds + a.D + 2) * pow2f(-t_in), lds_scalar(bias_lds + (8 * a.D) * 32));
+            }
+            if (!(a.use_viewdirs && l == a.D) && ((a.skip_in_mask >> l) & 1)) {
                 // h = cat[input_pts, h] (nerf.py:79-80): bring the encoded inputs to this layer's scale
-                rescale_tile(xp0, t_cur - t_pe);
-                rescale_tile(xp1, t_cur - t_pe);
-                t_pe = t_cur;
-                chunk_ktile8(pipe, cur, acc, xp0);
-                chunk_ktile8(pipe, cur, acc, xp1);
+                rescale_tile(xp0, t_in - t_pe);
+                rescale_tile(xp1, t_in - t_pe);
+                t_pe = t_in;
+                chunk_ktile8<-1, false>(pipe, cur, out, xp0, hid, pend, pd);
+                chunk_ktile8<-1, false>(pipe, cur, out, xp1, hid, pend, pd);
+                m_in = fmaxf(m_in, m_pe);
             }
+            make_pending(l, m_in, t_in);
+        };
+        int l = 1;
+        bool pend_in_a = true;
+        while (l < n_layers) {
+            layer_pass(accA, accB, l);
+            ++l;
+            pend_in_a = false;
+            if (l >= n_layers) break;
+            layer_pass(accB, accA, l);
+            ++l;
+            pend_in_a = true;
+        }
+        if (!pend_in_a) {
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt) chunk_ktile8(pipe, cur, acc, hid[kt]);
-            float m = half_max(finish_layer<8>(y, acc, bias_lds, is_feature ? 8 * a.D + 1 : 8 * i, h, c,
-                                               is_feature ? -__builtin_inff() : 0.0f));
-            if (i == a.D - 1 && a.use_viewdirs) {
-                // alpha_linear reads the post-ReLU trunk output (nerf.py:86): one row, as a dot product
-                sigma = row_dot<8>(y, bias_lds, 8 * a.D + 14, h) + lds_scalar(bias_lds + (8 * a.D) * 32);
-            }
-            if (is_feature) m = fmaxf(m, m_dd);
-            else if ((a.skip_in_mask >> (i + 1)) & 1) m = fmaxf(m, m_pe);
-            t_cur = pick_exponent(m);
-            const float sc = pow2f(t_cur);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) split_tile(hid[t], y[t], sc);
+            for (int t = 0; t < 8; ++t) accA[t] = accB[t];
         }
 
         const bool live = pt_raw < a.n_points;
         if (a.use_viewdirs) {
-            // views_linears[0] on cat[feature, gamma(dir)] (nerf.py:93-98): 4 output tiles
-            rescale_tile(xd, t_cur - t_dd);
-            zero_tiles<4>(acc);
-#pragma unroll
-            for (int kp = 0; kp < 4; ++kp) chunk_pair4(pipe, cur, acc, hid[2 * kp], hid[2 * kp + 1]);
-            chunk_ktile4(pipe, cur, acc, xd);
-            finish_layer<4>(y, acc, bias_lds, 8 * a.D + 9, h, lds_scalar(descale_lds + a.D + 1) * pow2f(-t_cur), 0.0f);
+            // views_linears[0] on cat[feature, gamma(dir)] (nerf.py:93-98): 4 output tiles; the pending layer is
+            // feature_linear
+            convert_tile<0>(hid[0], accA[0], pd);
+            convert_tile<1>(hid[1], accA[1], pd);
+            chunk_pair4<2, true>(pipe, cur, accB, hid[0], hid[1], hid, accA, pd);
+            chunk_pair4<4, false>(pipe, cur, accB, hid[2], hid[3], hid, accA, pd);
+            chunk_pair4<6, false>(pipe, cur, accB, hid[4], hid[5], hid, accA, pd);
+            chunk_pair4<-1, false>(pipe, cur, accB, hid[6], hid[7], hid, accA, pd);
+            close_pending();
+            XT xd;
+            {
+                f32x16 x0, x1, dd;
+                load_inputs<MODE>(a, pt, h, x0, x1, dd);
+                split_tile(xd, dd, pd.sc);
+            }
+            chunk_ktile4(pipe, cur, accB, xd);
+            f32x16 y[4];
+            finish_views(y, accB, bias0 + 128 * (8 * a.D + 9), lds_scalar(descale_lds + a.D + 1) * pow2f(-pd.t_out));
             // rgb_linear (nerf.py:101): three rows over the 128-wide view layer
             const float* rb = bias_lds + (8 * a.D + 13) * 32;
-            const float r0 = row_dot<4>(y, bias_lds, 8 * a.D + 22, h) + lds_scalar(rb);
-            const float r1 = row_dot<4>(y, bias_lds, 8 * a.D + 26, h) + lds_scalar(rb + 1);
-            const float r2 = row_dot<4>(y, bias_lds, 8 * a.D + 30, h) + lds_scalar(rb + 2);
+            const float r0 = row_dot4(y, bias0 + 128 * (8 * a.D + 22)) + lds_scalar(rb);
+            const float r1 = row_dot4(y, bias0 + 128 * (8 * a.D + 26)) + lds_scalar(rb + 1);
+            const float r2 = row_dot4(y, bias0 + 128 * (8 * a.D + 30)) + lds_scalar(rb + 2);
             if (live && h == 0) {
                 f32x4 o = {r0, r1, r2, sigma};   // outputs = cat[rgb, alpha] (nerf.py:106)
                 *(f32x4*)(a.out + pt * 4) = o;
             }
         } else {
-            // output_linear (nerf.py:109): rows 0..out_ch-1 of one tile
+            // output_linear (nerf.py:109): rows 0..out_ch-1 of one tile; the pending layer is trunk layer D-1
+            convert_tile<0>(hid[0], accA[0], pd);
+            convert_tile<1>(hid[1], accA[1], pd);
+            convert_tile<2>(hid[2], accA[2], pd);
+            convert_tile<3>(hid[3], accA[3], pd);
+            convert_tile<4>(hid[4], accA[4], pd);
+            convert_tile<5>(hid[5], accA[5], pd);
+            convert_tile<6>(hid[6], accA[6], pd);
+            convert_tile<7>(hid[7], accA[7], pd);
             f32x16 o;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = 0.0f;
-            chunk_row<8>(pipe, cur, o, hid);
-            Tile16 b = lds_tile_issue(bias_lds + ((8 * a.D) * 2 + h) * 16);
+            chunk_row8(pipe, cur, o, hid);
+            Tile16 b = lds_tile_issue(bias0 + 128 * (8 * a.D));
             lds_tile_wait(b);
-            const float c = lds_scalar(descale_lds + a.D) * pow2f(-t_cur);
+            const float c = lds_scalar(descale_lds + a.D) * pow2f(-pd.t_out);
             if (live) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -456,7 +610,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
 
 hipError_t launch_mlp_h2(const MlpLaunch& a, int mode, hipStream_t s) {
     if (a.n_points <= 0) return hipSuccess;
-    if (!a.stream_h2 || !a.descale) return hipErrorInvalidValue;
+    if (!a.stream_h2 || !a.descale || !a.gain) return hipErrorInvalidValue;
     const int64_t tiles = (a.n_points + kPointsPerGroup - 1) / kPointsPerGroup;
     static int n_cu[64] = {};
     int dev = 0;
@@ -545,6 +699,41 @@ __global__ __launch_bounds__(256) void convert_stream_h2_kernel(const float* str
         *(u32x4*)(dst + ((4 * u + 2 * s) * 64 + lane) * 4) = hi;
         *(u32x4*)(dst + ((4 * u + 2 * s + 1) * 64 + lane) * 4) = lo;
     }
+}
+
+// gain[2l] = max over output rows of sum_k |W[row][k]|, gain[2l+1] = max |bias|, for the layers whose outputs
+// are re-quantised (see Pending)
+__global__ __launch_bounds__(256) void layer_gain_kernel(const float* params, const GainRefs refs, float* gain) {
+    __shared__ float red[2][4];
+    const int l = blockIdx.x;
+    const float* w = params + refs.w_off[l];
+    const float* b = params + refs.b_off[l];
+    float g = 0.0f, bm = 0.0f;
+    for (int r = threadIdx.x; r < refs.out[l]; r += 256) {
+        float s = 0.0f;
+        for (int k = 0; k < refs.in[l]; ++k) s += fabsf(w[(size_t)r * refs.in[l] + k]);
+        g = fmaxf(g, s);
+        bm = fmaxf(bm, fabsf(b[r]));
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        g = fmaxf(g, __shfl_xor(g, o));
+        bm = fmaxf(bm, __shfl_xor(bm, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = g;
+        red[1][threadIdx.x >> 6] = bm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        gain[2 * l] = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        gain[2 * l + 1] = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    }
+}
+
+hipError_t launch_layer_gains(const float* params, const GainRefs& refs, float* gain, hipStream_t s) {
+    if (refs.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(layer_gain_kernel, dim3(refs.n), dim3(256), 0, s, params, refs, gain);
+    return hipGetLastError();
 }
 
 hipError_t launch_convert_stream_h2(const float* stream, const int* chunk_layer, int n_chunks, float* chunk_max,

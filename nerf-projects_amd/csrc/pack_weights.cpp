@@ -93,7 +93,7 @@ void row_tiles(std::vector<float>& out, const Linear& L, int row, int n_kt) {
 }  // namespace
 
 // Mirrors the chunk order pack_weights emits below: trunk layer i (hidden chunks, then its encoding chunks when it
-// reads cat[input_pts, h]), then feature_linear (id D) and views_linears.0 (id D+1), or output_linear (id D).
+// reads cat[input_pts, h]), then feature_linear (id D), the alpha_linear tile (id D+2) and views_linears.0 (id D+1), or output_linear (id D).
 std::vector<int> chunk_layers(const nerf_arch& a, uint32_t mask) {
     std::vector<int> ids;
     for (int i = 0; i < a.D; ++i) {
@@ -102,6 +102,7 @@ std::vector<int> chunk_layers(const nerf_arch& a, uint32_t mask) {
     }
     if (a.use_viewdirs) {
         ids.insert(ids.end(), 8, a.D);
+        ids.insert(ids.end(), 1, a.D + 2);   // the alpha_linear tile
         ids.insert(ids.end(), 5, a.D + 1);
     } else {
         ids.insert(ids.end(), 1, a.D);
@@ -209,6 +210,14 @@ int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors,
         bias_tiles(bias, feature, 8);
         for (int kt = 0; kt < 8; ++kt)
             chunk_ktile(st, feature, 8, [kt](int t, int h) { return hidden_col(kt, t, h); });
+        // alpha_linear once more as a one-row MFMA tile over the 8 k-tiles (group = kt*4 + t4), for the fp16-pair
+        // kernel, whose vector pipe is busy converting activations; the fp32 kernel passes over this chunk
+        {
+            float* c = st.new_chunk();
+            for (int kt = 0; kt < 8; ++kt)
+                for (int t4 = 0; t4 < 4; ++t4)
+                    fill_group(c, kt * 4 + t4, alpha, 0, t4, [kt](int t, int h) { return hidden_col(kt, t, h); });
+        }
         // views_linears.0 (nerf.py:93-98): input cat[feature(W), gamma(dir)], 4 output tiles.
         // two feature k-tiles per chunk: group = (ktl*4 + ot)*4 + t4
         bias_tiles(bias, views, 4);
