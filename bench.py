@@ -13,9 +13,11 @@ architecture (no checkpoint or dataset exists offline).
 
 1 ray-sample = 1 MLP point evaluation; a 64+128 ray costs 64 + 192 = 256 of them
 (1,186,816 FLOP each). `value` is the whole-job rate over all N GPUs.
-The roofline object prices the fused encode+MLP kernel against the dense fp32 MFMA peak
-(157.3 TFLOP/s, MI355X_MICROARCH.md) using HIP events recorded on its launch stream inside the
-timed region. The cpu_baseline object times the CPU oracle (numpy port, oracle/nerf_oracle.py) on
+The roofline object prices the fused encode+MLP kernel with HIP events recorded on its launch stream
+inside the timed region. Default arithmetic ("f16x2"): every fp32 operand is carried exactly as two fp16
+halves and every product costs three v_mfma_f32_32x32x16_f16, so the algorithmic FLOP rate is priced
+against one third of the dense fp16 MFMA peak (2516.6 / 3 = 838.9 TFLOP/s, MI355X_MICROARCH.md);
+`--precision f32` runs the v_mfma_f32_32x32x2_f32 kernel, priced against 157.3 TFLOP/s. The cpu_baseline object times the CPU oracle (numpy port, oracle/nerf_oracle.py) on
 a bounded sample of the same rays; it is reported next to the GPU number, never used by it.
 """
 import argparse
@@ -33,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_EVAL = 1186816          # 2 * 593,408 MACs
 PEAK_FP32_MFMA_TFLOPS = 157.3    # dense v_mfma_f32_32x32x2_f32 peak, MI355X_MICROARCH.md
+PEAK_FP16_MFMA_TFLOPS = 2516.6   # dense v_mfma_f32_32x32x16_f16 peak: 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz
 
 WORKLOADS = {
     # name: (H, W, N_samples, N_importance, ndc, white_bkgd)
@@ -49,6 +52,8 @@ def parse():
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--workload", default="lego_800x800_64c+128f", choices=sorted(WORKLOADS))
     p.add_argument("--chunk", type=int, default=32768)
+    p.add_argument("--precision", default=None, choices=["f16x2", "f32"],
+                   help="arithmetic of the fused MLP kernel (default: the library's, f16x2)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--force-collective", action="store_true",
@@ -84,12 +89,14 @@ def cpu_baseline(sample_rays, sd_c, sd_f, Sc, Si, white, target_s):
                               f"{n / dt:.0f} rays/s"}
 
 
-def pmc_traffic():
+def pmc_traffic(precision):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this
-    same command (profiles/rNN_pmc_summary.json, newest round; FETCH_SIZE doubled as the MI355X guide
-    prescribes for gfx950, WRITE_SIZE as read). bench.py itself cannot read PMC counters."""
+    same command (profiles/rNN_pmc_summary.json for f16x2, rNN_pmc_summary_f32.json for --precision f32,
+    newest round; FETCH_SIZE doubled as the MI355X guide prescribes for gfx950, WRITE_SIZE as read).
+    bench.py itself cannot read PMC counters."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    suffix = "" if precision == "f16x2" else "_" + precision
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_summary{suffix}.json")))
     if not files:
         return None, None
     s = json.load(open(files[-1]))
@@ -135,6 +142,9 @@ def main():
     del packed
     evals_per_ray = Sc + (Sc + Si if Si else 0)
     ctx = N.get_context()
+    if args.precision:
+        ctx.set_precision(args.precision)
+    precision = ctx.get_precision()
 
     def step():
         ret = N.batchify_rays(shard, args.chunk, **kw)
@@ -178,21 +188,38 @@ def main():
         flop_per_launch = pts_sum / max(launches_sum, 1) * FLOP_PER_EVAL
         avg_launch_s = mlp_ms_sum / max(launches_sum, 1) * 1e-3
         achieved = flop_per_launch / max(avg_launch_s, 1e-12) / 1e12
-        traffic, traffic_src = pmc_traffic() if args.workload == "lego_800x800_64c+128f" else (None, None)
+        traffic, traffic_src = pmc_traffic(precision) if args.workload == "lego_800x800_64c+128f" else (None, None)
+        if precision == "f16x2":
+            products = 3          # W_lo*x_hi + W_hi*x_lo + W_hi*x_hi per term
+            peak = PEAK_FP16_MFMA_TFLOPS / products
+            arith = {"dtype": "f32 operands as exact fp16 pairs, fp32 accumulate (v_mfma_f32_32x32x16_f16 x3)",
+                     "kernel": "nerf_mlp_h2_kernel<rays>", "mfma_pipe": "f16", "mfma_pipe_peak": PEAK_FP16_MFMA_TFLOPS,
+                     "mfma_products_per_term": products, "mfma_executed": achieved * products,
+                     "vs_f32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS}
+        else:
+            peak = PEAK_FP32_MFMA_TFLOPS
+            arith = {"dtype": "f32 (v_mfma_f32_32x32x2_f32)", "kernel": "nerf_mlp_kernel<rays>", "mfma_pipe": "f32",
+                     "mfma_pipe_peak": PEAK_FP32_MFMA_TFLOPS, "mfma_products_per_term": 1, "mfma_executed": achieved,
+                     "vs_f32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS}
         out = {
             "metric": "ray_samples_per_sec", "value": value, "unit": "ray-samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": arith["dtype"],
             "data": "synthetic",
             "config": {"workload": args.workload, "rays_per_frame": n_total, "N_samples": Sc, "N_importance": Si,
                        "evals_per_ray": evals_per_ray, "chunk": args.chunk, "netdepth": 8, "netwidth": 256,
+                       "precision": precision,
                        "parallelism": f"ray-shard x{world} + gather" if world > 1 else "single GPU"},
             "rays_per_sec": n_total * args.steps / dt,
             "ray_samples_per_sec_per_gpu": value / world,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                          "traffic_source": traffic_src,
-                         "kernel": "nerf_mlp_kernel<rays>", "launches": int(launches_sum),
+                         "kernel": arith["kernel"], "mfma_pipe": arith["mfma_pipe"],
+                         "mfma_pipe_peak": arith["mfma_pipe_peak"],
+                         "mfma_products_per_term": arith["mfma_products_per_term"],
+                         "mfma_executed": arith["mfma_executed"], "vs_f32_mfma_peak": arith["vs_f32_mfma_peak"],
+                         "launches": int(launches_sum),
                          "avg_launch_ms": avg_launch_s * 1e3, "flop_per_launch": flop_per_launch,
                          "kernel_time_share": mlp_ms_sum * 1e-3 / world / dt},
         }

@@ -71,10 +71,12 @@ void nerf_ctx_destroy(nerf_ctx* ctx);
  * activations between layers and everything outside the MLP are fp32 in both modes (the reference sets
  * torch.float32, nerf.ipynb:76); the modes differ in how the 256-wide contractions are evaluated:
  *   NERF_PRECISION_F32    v_mfma_f32_32x32x2_f32: an fp32 fmaf chain (24-bit operands).
- *   NERF_PRECISION_F16X2  every operand split exactly into two fp16 numbers (22 bits), scaled per layer
- *                         (weights) and per point (activations) by powers of two, three
- *                         v_mfma_f32_32x32x16_f16 products per term, fp32 accumulation. Error of a
- *                         256-long dot product: 0.5-1.0 eps(fp32) rms vs 0.4-0.5 for the fmaf chain.
+ *   NERF_PRECISION_F16X2  every operand carried as two round-to-nearest fp16 numbers hi + lo (|v - hi - lo| <=
+ *                         2^-24 |v|, what fp32 keeps), scaled per layer (weights) and per point (activations) by
+ *                         powers of two so nothing leaves the fp16 range; three v_mfma_f32_32x32x16_f16
+ *                         products per term (lo*lo is below fp32 resolution), fp32 accumulation.
+ * A context starts in NERF_PRECISION_F16X2 (2.9x the frame rate, errors against an fp64 evaluation of the
+ * network equal or smaller than the fp32 chain's: tests/test_hip_parity.py::test_mlp_precisions_vs_fp64).
  * Takes effect for the following calls on this context; weights loaded earlier stay valid. */
 #define NERF_PRECISION_F32 0
 #define NERF_PRECISION_F16X2 1

@@ -18,7 +18,7 @@
 
 struct nerf_ctx {
     int device = 0;
-    int precision = NERF_PRECISION_F32;   // arithmetic of the fused MLP kernel (nerf_set_precision)
+    int precision = NERF_PRECISION_F16X2;   // arithmetic of the fused MLP kernel (nerf_set_precision)
     nerf::PackedNet nets[NERF_NUM_SLOTS];
     char* ws = nullptr;          // workspace arena
     size_t ws_bytes = 0;

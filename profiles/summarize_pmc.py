@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc passes of bench.py into profiles/<tag>_pmc_summary.{json,md}.
 
-Usage: python profiles/summarize_pmc.py <tag> <dir with pmc_fetch/ pmc_write/ pmc_sq/ pmc_l2/>
+Usage: python profiles/summarize_pmc.py <tag> <dir with pmc_fetch/ pmc_write/ pmc_sq/ pmc_l2/> [--kernel NAME]
+(<tag> like r01 for the default fp16-pair kernel, r01_f32 with --kernel nerf_mlp_kernel for the fp32 one)
 Each pass is its own run (`rocprofv3 --pmc ... --kernel-trace --output-format csv`), as the MI355X
 guide prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass). FETCH_SIZE/WRITE_SIZE are in KiB.
 On gfx950 FETCH_SIZE under-reports wide (16 B/lane) streaming reads by 2x; the kernel's dominant read
@@ -13,7 +14,7 @@ import sys
 
 import pandas as pd
 
-KERNEL = "nerf_mlp_kernel"
+KERNEL = "nerf_mlp_h2_kernel"   # pass --kernel nerf_mlp_kernel for the fp32 kernel
 
 
 def load(root, name):
@@ -46,8 +47,10 @@ def main(tag, root):
     out["mfma_busy_frac_of_2.4GHz_x_1024_simd"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (dur * 2.4 * 1024)
     out["wait_any_frac_of_wave_cycles"] = per["SQ_WAIT_ANY"] / per["SQ_WAVE_CYCLES"]
     out["lds_bank_conflict_cycles"] = per["SQ_LDS_BANK_CONFLICT"]
-    json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
-    with open(f"profiles/{tag}_pmc_summary.md", "w") as f:
+    rnd, _, suffix = tag.partition("_")
+    stem = f"profiles/{rnd}_pmc_summary" + (f"_{suffix}" if suffix else "")
+    json.dump(out, open(stem + ".json", "w"), indent=1)
+    with open(stem + ".md", "w") as f:
         f.write(f"# {tag}: PMC summary for `{KERNEL}` (bench.py --steps 1 --warmup 0 --no-cpu-baseline)\n\n")
         f.write("Mean per launch over the 40 launches of one 800x800 64+128 frame (20 coarse + 20 fine).\n\n")
         f.write("| quantity | value |\n|---|---|\n")
@@ -61,4 +64,8 @@ def main(tag, root):
 
 
 if __name__ == "__main__":
+    if "--kernel" in sys.argv:
+        i = sys.argv.index("--kernel")
+        KERNEL = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
     main(sys.argv[1], sys.argv[2])
