@@ -1,5 +1,5 @@
 #!/bin/bash
-# round measurement: bench lines, rocprofv3 kernel stats and the four PMC passes of the default (fp16-pair) kernel
+# round measurement (run on the GPU box: gpurun -- bash profiles/measure.sh): bench lines, rocprofv3 kernel stats and the four PMC passes of the default (fp16-pair) kernel
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/measure; rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
