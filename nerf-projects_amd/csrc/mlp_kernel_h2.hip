@@ -54,6 +54,12 @@ struct PipeH {
     const char* stream;
     char* lds;
     int c, b, n, wave, lane;
+    // LDS-DMA source / destination of the chunk being consumed (set once per chunk, consume_chunk): its
+    // first-half steps move pieces 4..7 of chunk c+2, its second-half steps pieces 0..3 of chunk c+3
+    const char* g_first;
+    const char* g_second;
+    char* l_first;
+    char* l_second;
 };
 
 __device__ __forceinline__ int ringh_next(int b, int k) {
@@ -61,17 +67,22 @@ __device__ __forceinline__ int ringh_next(int b, int k) {
     return b >= kRingH ? b - kRingH : b;
 }
 
-template <int I>
-__device__ __forceinline__ void prefetch_piece(const PipeH& p, int chunk, int slot) {
-    const char* g = p.stream + (size_t)chunk * kChunkBytes + p.wave * 8192 + p.lane * 16 + I * 1024;
-    char* l = p.lds + slot * kChunkBytes + p.wave * 8192 + I * 1024;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(l), 16, 0, 0);
+__device__ __forceinline__ const char* piece_src(const PipeH& p, int chunk) {
+    return p.stream + (size_t)chunk * kChunkBytes + p.wave * 8192 + p.lane * 16;
+}
+__device__ __forceinline__ char* piece_dst(const PipeH& p, int slot) { return p.lds + slot * kChunkBytes + p.wave * 8192; }
+
+// piece J (0..3) of a half chunk: the instruction's immediate offset moves the global and the LDS address together,
+// so the four pieces of a half share one address register pair and one M0 value
+template <int J>
+__device__ __forceinline__ void prefetch_piece(const char* g, char* l) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(l), 16, J * 1024, 0);
 }
 template <int LO, int HI>
-__device__ __forceinline__ void prefetch_pieces(const PipeH& p, int chunk, int slot) {
+__device__ __forceinline__ void prefetch_pieces(const char* g, char* l) {
     if constexpr (LO < HI) {
-        prefetch_piece<LO>(p, chunk, slot);
-        prefetch_pieces<LO + 1, HI>(p, chunk, slot);
+        prefetch_piece<LO>(g, l);
+        prefetch_pieces<LO + 1, HI>(g, l);
     }
 }
 
@@ -141,13 +152,8 @@ __device__ __forceinline__ void run_steps(PipeH& p, Frag4& cur, const f32x4* fr,
         // MI355X_MICROARCH.md - and between the later MFMAs, next to the conversion work, it cost 9 % more)
 #ifndef NERF_ABLATE_DMA
         constexpr int per = 8 / NSTEP;   // pieces per step
-        if constexpr (S < NSTEP / 2) {
-            const int nx = p.c + 2 < p.n ? p.c + 2 : p.c + 2 - p.n;   // wraps into the next tile's stream
-            prefetch_pieces<4 + S * per, 4 + (S + 1) * per>(p, nx, ringh_next(p.b, 2));
-        } else {
-            const int nx = p.c + 3 < p.n ? p.c + 3 : p.c + 3 - p.n;
-            prefetch_pieces<(S - NSTEP / 2) * per, (S - NSTEP / 2 + 1) * per>(p, nx, ringh_next(p.b, 3));
-        }
+        if constexpr (S < NSTEP / 2) prefetch_pieces<S * per, (S + 1) * per>(p.g_first, p.l_first);
+        else prefetch_pieces<(S - NSTEP / 2) * per, (S - NSTEP / 2 + 1) * per>(p.g_second, p.l_second);
 #endif
         __builtin_amdgcn_sched_barrier(0);
         body(StepTag<S>{}, PartTag<1>{}, cur);
@@ -179,6 +185,12 @@ template <int NSTEP, int VALU_PER_MFMA, class Body>
 __device__ __forceinline__ void consume_chunk(PipeH& p, Frag4& cur, Body body) {
     const f32x4* fr = ring_frags(p, p.b);
     const f32x4* fr_next = ring_frags(p, ringh_next(p.b, 1));
+    const int c2 = p.c + 2 < p.n ? p.c + 2 : p.c + 2 - p.n;   // wraps into the next tile's stream
+    const int c3 = p.c + 3 < p.n ? p.c + 3 : p.c + 3 - p.n;
+    p.g_first = piece_src(p, c2) + 4096;
+    p.l_first = piece_dst(p, ringh_next(p.b, 2)) + 4096;
+    p.g_second = piece_src(p, c3);
+    p.l_second = piece_dst(p, ringh_next(p.b, 3));
     run_steps<0, NSTEP, VALU_PER_MFMA>(p, cur, fr, fr_next, body);
     ++p.c;
     p.b = ringh_next(p.b, 1);
@@ -447,10 +459,12 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
 
-    PipeH pipe{(const char*)a.stream_h2, ring_lds, 0, 0, a.n_chunks, wave, lane};
-    prefetch_pieces<0, 8>(pipe, 0, 0);
-    prefetch_pieces<0, 8>(pipe, 1, 1);
-    prefetch_pieces<0, 4>(pipe, 2, 2);   // chunk 0's first-half steps issue the other four
+    PipeH pipe{(const char*)a.stream_h2, ring_lds, 0, 0, a.n_chunks, wave, lane, nullptr, nullptr, nullptr, nullptr};
+    for (int k = 0; k < 2; ++k) {
+        prefetch_pieces<0, 4>(piece_src(pipe, k), piece_dst(pipe, k));
+        prefetch_pieces<0, 4>(piece_src(pipe, k) + 4096, piece_dst(pipe, k) + 4096);
+    }
+    prefetch_pieces<0, 4>(piece_src(pipe, 2), piece_dst(pipe, 2));   // chunk 0's first-half steps issue the other four
     for (int i = threadIdx.x; i < a.n_bias_tiles * kBiasTileFloats; i += 256) bias_lds[i] = a.bias[i];
     if (threadIdx.x < a.D + 3) descale_lds[threadIdx.x] = a.descale[threadIdx.x];
     if (threadIdx.x < 2 * (a.D + 1)) gain_lds[threadIdx.x] = a.gain[threadIdx.x];
