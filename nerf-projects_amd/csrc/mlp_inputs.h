@@ -12,69 +12,86 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
 // ---- inputs -----------------------------------------------------------------------------
-// Slot maps of the encoded tiles (must match pack_weights.cpp).
-__host__ __device__ constexpr int pe_col_xyz(int s, int h) {
-    return s < 30 ? 3 + 6 * (s / 3) + 3 * h + (s % 3) : (s == 30 ? (h ? 2 : 0) : (h ? -1 : 1));
-}
-__host__ __device__ constexpr int pe_col_dir(int t, int h) {
-    return t < 12 ? 3 + 6 * (t / 3) + 3 * h + (t % 3) : (t == 12 ? (h ? 2 : 0) : (t == 13 ? (h ? -1 : 1) : -1));
-}
-
-// gamma(xyz) and gamma(dir) of one point in the tile layout: half-wave 0 keeps the sines,
-// half-wave 1 the cosines. x*2^k is exact in fp32 (embedder.py:48,61); sincosf is the
+// gamma(xyz) and gamma(dir) of one point in the tile layout (slot maps: nerf_internal.h, pe_col_*): half-wave 0
+// keeps the sines, half-wave 1 the cosines. Both half-waves of a point would evaluate the same 30 (12) sincosf,
+// so they share the work: half-wave 0 runs the low five (two) frequencies, half-wave 1 the high ones on
+// coordinates pre-multiplied by 2^5 (2^2); each lane keeps the component it owns and hands the other one to its
+// partner lane (one __shfl_xor(.,32) per slot). x*2^k is exact in fp32 (embedder.py:48,61); sincosf is the
 // accurate ocml routine (not v_sin_f32): arguments reach |x|*512.
+template <bool WANT_XYZ, bool WANT_DIR>
 __device__ __forceinline__ void encode_point(const float (&p)[3], const float (&d)[3], int h, bool dirs,
                                              f32x16& x0, f32x16& x1, f32x16& dd) {
+    if constexpr (WANT_XYZ) {
+        const float sc = h ? 32.0f : 1.0f;
+        const float q[3] = {p[0] * sc, p[1] * sc, p[2] * sc};
 #pragma unroll
-    for (int s = 0; s < 30; ++s) {
-        float sn, cs;
-#ifdef NERF_ABLATE_PE
-        sn = p[s % 3] * (float)(1 << (s / 3)); cs = sn + 1.0f;
-#else
-        sincosf(p[s % 3] * (float)(1 << (s / 3)), &sn, &cs);
-#endif
-        const float v = h ? cs : sn;
-        if (s < 16) x0[s] = v; else x1[s - 16] = v;
-    }
-    x1[14] = h ? p[2] : p[0];
-    x1[15] = h ? 0.0f : p[1];
-    if (dirs) {
-#pragma unroll
-        for (int t = 0; t < 12; ++t) {
+        for (int j = 0; j < 15; ++j) {
             float sn, cs;
 #ifdef NERF_ABLATE_PE
-            sn = d[t % 3] * (float)(1 << (t / 3)); cs = sn + 1.0f;
+            sn = q[j % 3] * (float)(1 << (j / 3)); cs = sn + 1.0f;
 #else
-            sincosf(d[t % 3] * (float)(1 << (t / 3)), &sn, &cs);
+            sincosf(q[j % 3] * (float)(1 << (j / 3)), &sn, &cs);
 #endif
-            dd[t] = h ? cs : sn;
+            const float own = h ? cs : sn;
+            const float other = __shfl_xor(h ? sn : cs, 32);
+            x0[j] = own;                                   // slot j
+            if (j == 0) x0[15] = other; else x1[j - 1] = other;   // slot j + 15
         }
-        dd[12] = h ? d[2] : d[0];
-        dd[13] = h ? 0.0f : d[1];
-        dd[14] = 0.0f;
-        dd[15] = 0.0f;
-    } else {
+        x1[14] = h ? p[2] : p[0];
+        x1[15] = h ? 0.0f : p[1];
+    }
+    if constexpr (WANT_DIR) {
+        if (dirs) {
+            const float sc = h ? 4.0f : 1.0f;
+            const float q[3] = {d[0] * sc, d[1] * sc, d[2] * sc};
 #pragma unroll
-        for (int t = 0; t < 16; ++t) dd[t] = 0.0f;
+            for (int j = 0; j < 6; ++j) {
+                float sn, cs;
+#ifdef NERF_ABLATE_PE
+                sn = q[j % 3] * (float)(1 << (j / 3)); cs = sn + 1.0f;
+#else
+                sincosf(q[j % 3] * (float)(1 << (j / 3)), &sn, &cs);
+#endif
+                dd[j] = h ? cs : sn;
+                dd[j + 6] = __shfl_xor(h ? sn : cs, 32);
+            }
+            dd[12] = h ? d[2] : d[0];
+            dd[13] = h ? 0.0f : d[1];
+            dd[14] = 0.0f;
+            dd[15] = 0.0f;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) dd[t] = 0.0f;
+        }
     }
 }
 
-template <int MODE>
+// WANT_XYZ / WANT_DIR: which tiles the caller uses (the other is left untouched). dir_max: largest |component| of the
+// direction (an upper bound of |gamma(dir)| together with 1), or of the encoded direction columns in embedded mode.
+template <int MODE, bool WANT_XYZ = true, bool WANT_DIR = true>
 __device__ __forceinline__ void load_inputs(const MlpLaunch& a, int64_t pt, int h, f32x16& x0, f32x16& x1,
-                                            f32x16& dd) {
+                                            f32x16& dd, float* dir_max = nullptr) {
     if (MODE == kInputEmbedded) {
         const float* row = a.x + pt * a.x_ld;
+        if constexpr (WANT_XYZ) {
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            const int c = h ? pe_col_xyz(s, 1) : pe_col_xyz(s, 0);
-            const float v = (c >= 0 && c < a.in_ch) ? row[c] : 0.0f;
-            if (s < 16) x0[s] = v; else x1[s - 16] = v;
+            for (int s = 0; s < 32; ++s) {
+                const int c = h ? pe_col_xyz(s, 1) : pe_col_xyz(s, 0);
+                const float v = (c >= 0 && c < a.in_ch) ? row[c] : 0.0f;
+                if (s < 16) x0[s] = v; else x1[s - 16] = v;
+            }
         }
+        float m = 0.0f;
+        if (WANT_DIR || dir_max) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int c = h ? pe_col_dir(t, 1) : pe_col_dir(t, 0);
-            dd[t] = (a.use_viewdirs && c >= 0 && c < a.in_ch_views) ? row[a.in_ch + c] : 0.0f;
+            for (int t = 0; t < 16; ++t) {
+                const int c = h ? pe_col_dir(t, 1) : pe_col_dir(t, 0);
+                const float v = (a.use_viewdirs && c >= 0 && c < a.in_ch_views) ? row[a.in_ch + c] : 0.0f;
+                if constexpr (WANT_DIR) dd[t] = v;
+                m = fmaxf(m, fabsf(v));
+            }
         }
+        if (dir_max) *dir_max = fmaxf(m, __shfl_xor(m, 32));
         return;
     }
     float p[3], d[3] = {0.0f, 0.0f, 0.0f};
@@ -100,7 +117,8 @@ __device__ __forceinline__ void load_inputs(const MlpLaunch& a, int64_t pt, int 
             d[2] = r[a.ray_ld - 1];
         }
     }
-    encode_point(p, d, h, a.use_viewdirs != 0, x0, x1, dd);
+    if (dir_max) *dir_max = fmaxf(fmaxf(fabsf(d[0]), fabsf(d[1])), fmaxf(fabsf(d[2]), 1.0f));
+    encode_point<WANT_XYZ, WANT_DIR>(p, d, h, a.use_viewdirs != 0, x0, x1, dd);
 }
 
 }  // namespace nerf

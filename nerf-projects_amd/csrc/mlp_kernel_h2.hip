@@ -485,12 +485,11 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
         int t_pe;
         {
             f32x16 x0, x1, dd;
-            load_inputs<MODE>(a, pt, h, x0, x1, dd);
+            load_inputs<MODE, true, false>(a, pt, h, x0, x1, dd, &m_dd);   // gamma(dir) itself waits for the view layer
             m_pe = half_max(tile_absmax(x1, tile_absmax(x0, 0.0f)));
-            m_dd = half_max(tile_absmax(dd, 0.0f));
             t_pe = pick_exponent(m_pe);
             split_tile(xp0, x0, pow2f(t_pe));
-            split_tile(xp1, x1, pow2f(t_pe));   // gamma(dir) is re-derived at the view layer: 16 registers for 9 layers
+            split_tile(xp1, x1, pow2f(t_pe));
         }
 
         XT hid[8];
@@ -584,7 +583,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             XT xd;
             {
                 f32x16 x0, x1, dd;
-                load_inputs<MODE>(a, pt, h, x0, x1, dd);
+                load_inputs<MODE, false, true>(a, pt, h, x0, x1, dd);
                 split_tile(xd, dd, pd.sc);
             }
             chunk_ktile4(pipe, cur, accB, xd);

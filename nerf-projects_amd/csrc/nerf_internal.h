@@ -25,6 +25,24 @@ constexpr int kPointsPerWave = 32;
 constexpr int kWavesPerGroup = 4;
 constexpr int kPointsPerGroup = kPointsPerWave * kWavesPerGroup;
 
+// ---- slot maps of the encoded tiles (kernel input side: mlp_inputs.h; weight side: pack_weights.cpp) ----------
+// Column of gamma(xyz) (nerf/embedder.py:28-65: [x y z | sin f0 xyz | cos f0 xyz | ...], 63 wide) held by slot
+// s = 16*tile + t of half-wave h, or -1 for padding. Half-wave 0 holds sines, half-wave 1 cosines; slots 0..14 are
+// the five frequencies the half-wave evaluates itself (0-4 for h = 0, 5-9 for h = 1), slots 15..29 the five its
+// partner evaluates; slots 30, 31 the raw coordinates.
+__host__ __device__ constexpr int pe_col_xyz(int s, int h) {
+    return s < 15 ? 3 + 6 * (s / 3 + 5 * h) + 3 * h + (s % 3)
+         : s < 30 ? 3 + 6 * ((s - 15) / 3 + 5 * (1 - h)) + 3 * h + (s % 3)
+         : s == 30 ? (h ? 2 : 0) : (h ? -1 : 1);
+}
+// Column of gamma(dir) (27 wide) held by slot t of the single direction tile: slots 0..5 own frequencies
+// (0-1 / 2-3), 6..11 the partner's, 12, 13 the raw components.
+__host__ __device__ constexpr int pe_col_dir(int t, int h) {
+    return t < 6 ? 3 + 6 * (t / 3 + 2 * h) + 3 * h + (t % 3)
+         : t < 12 ? 3 + 6 * ((t - 6) / 3 + 2 * (1 - h)) + 3 * h + (t % 3)
+         : t == 12 ? (h ? 2 : 0) : (t == 13 ? (h ? -1 : 1) : -1);
+}
+
 // one nn.Linear inside the flat parameter buffer (state_dict order: weight [out,in] then bias [out])
 struct LinearDesc {
     int out = 0, in = 0;

@@ -11,9 +11,8 @@
 // with no cross-lane movement, provided the A operand of that k-step holds
 // W[out_row = 32*ot + (lane & 31)][f(tile, t, h)]. That permutation is applied here, once.
 //
-// Positional-encoding tiles use their own slot map (see pe_col_*): half-wave h = 0 holds
-// the sines, h = 1 the cosines of the same (frequency, component), so each lane runs one
-// sincosf per slot and keeps the half it owns.
+// Positional-encoding tiles use their own slot map (pe_col_* in nerf_internal.h): half-wave h = 0 holds
+// the sines, h = 1 the cosines; the two half-waves split the frequencies between them.
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -25,22 +24,6 @@ namespace nerf {
 namespace {
 
 inline int hidden_col(int tile, int t, int h) { return 32 * tile + (t & 3) + 8 * (t >> 2) + 4 * h; }
-
-// Column of gamma(xyz) (nerf/embedder.py:28-65: [x y z | sin f0 xyz | cos f0 xyz | ...]) held
-// by slot s = 16*tile + t of half-wave h, or -1 for padding.
-inline int pe_col_xyz(int s, int h) {
-    if (s < 30) return 3 + 6 * (s / 3) + 3 * h + (s % 3);
-    if (s == 30) return h ? 2 : 0;
-    return h ? -1 : 1;
-}
-
-// Column of gamma(dir) (27 wide) held by slot t of the single direction tile.
-inline int pe_col_dir(int t, int h) {
-    if (t < 12) return 3 + 6 * (t / 3) + 3 * h + (t % 3);
-    if (t == 12) return h ? 2 : 0;
-    if (t == 13) return h ? -1 : 1;
-    return -1;
-}
 
 struct Stream {
     std::vector<float> data;
