@@ -284,6 +284,11 @@ __device__ __forceinline__ float lds_scalar(const float* p) {
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds_addr(p)) : "memory");
     return v;
 }
+__device__ __forceinline__ f32x4 lds_vec4(const float* p) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds_addr(p)) : "memory");
+    return v;
+}
 // the two bias entries of one register pair, `OFF` bytes past `addr`; issued one step ahead of their use
 template <int OFF>
 __device__ __forceinline__ f32x2 lds_pair_issue(unsigned addr) {
@@ -453,8 +458,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
     // The ring is the dynamic LDS allocation; the bias block and the small per-layer tables are static.
     extern __shared__ __attribute__((aligned(16))) char ring_lds[];
     __shared__ __attribute__((aligned(16))) float bias_lds[kBiasLdsBytes / 4];
-    __shared__ float descale_lds[kMaxDepth + 3];
-    __shared__ float gain_lds[2 * (kMaxDepth + 2)];
+    __shared__ __attribute__((aligned(16))) float layer_tab[4 * (kMaxDepth + 3)];   // per layer [descale, gain, max|b|, -]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
@@ -466,8 +470,14 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
     }
     prefetch_pieces<0, 4>(piece_src(pipe, 2), piece_dst(pipe, 2));   // chunk 0's first-half steps issue the other four
     for (int i = threadIdx.x; i < a.n_bias_tiles * kBiasTileFloats; i += 256) bias_lds[i] = a.bias[i];
-    if (threadIdx.x < a.D + 3) descale_lds[threadIdx.x] = a.descale[threadIdx.x];
-    if (threadIdx.x < 2 * (a.D + 1)) gain_lds[threadIdx.x] = a.gain[threadIdx.x];
+    if (threadIdx.x < a.D + 3) {
+        const int l = threadIdx.x;
+        const bool has_gain = l <= (a.use_viewdirs ? a.D : a.D - 1);
+        layer_tab[4 * l] = a.descale[l];
+        layer_tab[4 * l + 1] = has_gain ? a.gain[2 * l] : 0.0f;
+        layer_tab[4 * l + 2] = has_gain ? a.gain[2 * l + 1] : 0.0f;
+        layer_tab[4 * l + 3] = 0.0f;
+    }
     __syncthreads();   // chunks 0, 1, the bias block and the layer tables are in LDS
     Frag4 cur = read_frags(ring_frags(pipe, 0), 0);
 
@@ -502,9 +512,10 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
         // (true units), t_in = exponent its inputs were scaled by
         auto make_pending = [&](int l, float m_in, int t_in) {
             const bool is_feature = a.use_viewdirs && l == a.D;
-            pd.c = lds_scalar(descale_lds + l) * pow2f(-t_in);
+            const f32x4 tab = lds_vec4(layer_tab + 4 * l);   // one exposed LDS latency per layer instead of three
+            pd.c = tab[0] * pow2f(-t_in);
             pd.floor = is_feature ? -__builtin_inff() : 0.0f;
-            float bound = fmaf(lds_scalar(gain_lds + 2 * l), m_in, lds_scalar(gain_lds + 2 * l + 1)) * 1.001f;
+            float bound = fmaf(tab[1], m_in, tab[2]) * 1.001f;
             // the next layer may concatenate these outputs with inputs that must fit the same scale
             if (is_feature) bound = fmaxf(bound, m_dd);
             else if ((a.skip_in_mask >> (l + 1)) & 1) bound = fmaxf(bound, m_pe);
@@ -540,7 +551,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
                 // alpha_linear reads the post-ReLU trunk output (nerf.py:86), i.e. this layer's input: one more
                 // chunk, a single-row tile accumulated into a pending tile that is no longer needed
                 chunk_row8(pipe, cur, pend[0], hid);
-                sigma = fmaf(pend[0][0], lds_scalar(descale_lds + a.D + 2) * pow2f(-t_in), lds_scalar(bias_lds + (8 * a.D) * 32));
+                sigma = fmaf(pend[0][0], lds_scalar(layer_tab + 4 * (a.D + 2)) * pow2f(-t_in), lds_scalar(bias_lds + (8 * a.D) * 32));
             }
             if (!(a.use_viewdirs && l == a.D) && ((a.skip_in_mask >> l) & 1)) {
                 // h = cat[input_pts, h] (nerf.py:79-80): bring the encoded inputs to this layer's scale
@@ -588,7 +599,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             }
             chunk_ktile4(pipe, cur, accB, xd);
             f32x16 y[4];
-            finish_views(y, accB, bias0 + 128 * (8 * a.D + 9), lds_scalar(descale_lds + a.D + 1) * pow2f(-pd.t_out));
+            finish_views(y, accB, bias0 + 128 * (8 * a.D + 9), lds_scalar(layer_tab + 4 * (a.D + 1)) * pow2f(-pd.t_out));
             // rgb_linear (nerf.py:101): three rows over the 128-wide view layer
             const float* rb = bias_lds + (8 * a.D + 13) * 32;
             const float r0 = row_dot4(y, bias0 + 128 * (8 * a.D + 22)) + lds_scalar(rb);
@@ -612,7 +623,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             chunk_row8(pipe, cur, o, hid);
             Tile16 b = lds_tile_issue(bias0 + 128 * (8 * a.D));
             lds_tile_wait(b);
-            const float c = lds_scalar(descale_lds + a.D) * pow2f(-pd.t_out);
+            const float c = lds_scalar(layer_tab + 4 * a.D) * pow2f(-pd.t_out);
             if (live) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
