@@ -55,10 +55,28 @@ int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net, int mode, hipStream
         }
         HIP_TRY(hipEventRecord(e0, s));
     }
+#ifdef NERF_STAMPS
+    // diagnostic build: one wave of workgroup 0 samples s_memtime through its first tile; dumped after every launch
+    static unsigned long long* d_stamps = nullptr;
+    if (!d_stamps) HIP_TRY(hipMalloc((void**)&d_stamps, 8192 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d_stamps, 0, 8192 * sizeof(unsigned long long), s));
+    a.stamps = d_stamps;
+#endif
     if (c->precision == NERF_PRECISION_F16X2)
         HIP_TRY(launch_mlp_h2(a, mode, s));
     else
         HIP_TRY(launch_mlp(a, mode, s));
+#ifdef NERF_STAMPS
+    if (const char* path = getenv("NERF_STAMPS_FILE")) {
+        std::vector<unsigned long long> h(8192);
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(h.data(), d_stamps, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(path, "wb")) {
+            fwrite(h.data(), sizeof(h[0]), h.size(), f);
+            fclose(f);
+        }
+    }
+#endif
     if (c->profiling) {
         HIP_TRY(hipEventRecord(e1, s));
         c->events.emplace_back(e0, e1);

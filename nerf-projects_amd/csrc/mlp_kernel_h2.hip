@@ -40,6 +40,33 @@ __device__ __forceinline__ f32x16 mma(const f32x4& a, const u32x4& b, f32x16 c) 
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
 }
 
+#ifdef NERF_STAMPS
+// diagnostic build: wave 0 of workgroup 0 records (tag, s_memtime) through its first tile. A sample is taken at the
+// start of a step and stored at the start of the NEXT one, after the lgkmcnt(0) the step's first MFMA needs anyway, so
+// that reading the counter (an SMEM return) adds no wait of its own.
+struct Stamper {
+    unsigned long long* buf;
+    unsigned long long t_prev;
+    int tag_prev;
+    int n;
+    bool on;
+};
+__device__ __forceinline__ void stamp(Stamper& st, int tag) {
+    if (st.on) {
+        if (st.n < 4090 && (threadIdx.x & 63) == 0) {
+            st.buf[2 * st.n] = (unsigned long long)st.tag_prev;
+            st.buf[2 * st.n + 1] = st.t_prev;
+        }
+        ++st.n;
+        st.t_prev = __builtin_amdgcn_s_memtime();
+        st.tag_prev = tag;
+    }
+}
+#define STAMP(p, tag) stamp((p).st, (tag))
+#else
+#define STAMP(p, tag) do {} while (0)
+#endif
+
 // ---- weight-stream pipeline ------------------------------------------------------------
 // Four 32 KiB LDS buffers form a ring: while chunk c is consumed (48 MFMAs, ~1500 cycles), chunk c+1 is resident,
 // chunk c+2 half issued and chunk c+3 about to be. A chunk travels as 8 LDS-DMA pieces per wave (1 KiB each), and
@@ -60,6 +87,9 @@ struct PipeH {
     const char* g_second;
     char* l_first;
     char* l_second;
+#ifdef NERF_STAMPS
+    Stamper st;
+#endif
 };
 
 __device__ __forceinline__ int ringh_next(int b, int k) {
@@ -146,6 +176,7 @@ __device__ __forceinline__ void run_steps(PipeH& p, Frag4& cur, const f32x4* fr,
     if constexpr (S < NSTEP) {
         body(StepTag<S>{}, PartTag<0>{}, cur);
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(p, (p.c << 8) | (S << 4) | VALU_PER_MFMA);
         body(StepTag<S>{}, PartTag<2>{}, cur);   // before the fragment reads: lds_pair_wait counts on that
         Frag4 nxt = (S + 1 < NSTEP) ? read_frags(fr, (S + 1) * 4) : read_frags(fr_next, 0);
         // (the LDS-DMA pieces follow the reads: a piece stalls the issuing wave for 60+ cycles wherever it goes -
@@ -205,6 +236,12 @@ __device__ __forceinline__ int pick_exponent(float m) {
 __device__ __forceinline__ float pow2f(int t) { return __builtin_ldexpf(1.0f, t); }
 
 __device__ __forceinline__ float half_max(float m) { return fmaxf(m, __shfl_xor(m, 32)); }
+// largest value over the wavefront, as a wave-uniform number (lives in an SGPR)
+__device__ __forceinline__ float wave_max(float m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
+}
 
 __device__ __forceinline__ float tile_absmax(const f32x16& v, float m) {
 #pragma unroll
@@ -358,17 +395,17 @@ __device__ __forceinline__ void convert_tile(XT& dst, const f32x16& src, Pending
 template <int CONV, bool FIRST>
 __device__ __forceinline__ void chunk_ktile8(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x, XT (&hid)[8],
                                              const f32x16 (&pend)[8], Pending& pd) {
-    f32x2 r[2];
-    if constexpr (CONV >= 0) r[0] = lds_pair_issue<128 * (CONV < 0 ? 0 : CONV)>(pd.bias_addr);
+    constexpr int C0 = CONV < 0 ? 0 : CONV;
+    f32x2 r;   // requested at the end of the previous step (after that step's conversion): one register pair, not two
+    if constexpr (CONV >= 0) r = lds_pair_issue<128 * C0>(pd.bias_addr);
     consume_chunk<8, (CONV >= 0 ? 3 : 0)>(p, cur, [&](auto tag, auto part, const Frag4& f) {
         constexpr int s = decltype(tag)::value, pt = decltype(part)::value;
-        if constexpr (pt == 2) {
-            if constexpr (CONV >= 0 && s < 7) r[(s + 1) & 1] = lds_pair_issue<128 * (CONV < 0 ? 0 : CONV) + 8 * (s + 1)>(pd.bias_addr);
-        } else {
+        if constexpr (pt != 2) {
             mma_step<pt, FIRST>(acc[s], f, x);
             if constexpr (pt == 1 && CONV >= 0) {
-                lds_pair_wait<5>(r[s & 1]);
-                convert_pair<s>(hid[CONV < 0 ? 0 : CONV], pend[CONV < 0 ? 0 : CONV], pd, r[s & 1]);
+                lds_pair_wait<4>(r);   // newer: this step's four fragment reads
+                convert_pair<s>(hid[C0], pend[C0], pd, r);
+                if constexpr (s < 7) r = lds_pair_issue<128 * C0 + 8 * (s + 1)>(pd.bias_addr);
             }
         }
     });
@@ -464,6 +501,9 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
     const int h = lane >> 5;
 
     PipeH pipe{(const char*)a.stream_h2, ring_lds, 0, 0, a.n_chunks, wave, lane, nullptr, nullptr, nullptr, nullptr};
+#ifdef NERF_STAMPS
+    pipe.st = Stamper{a.stamps, 0, -1, 0, blockIdx.x == 0 && wave == 0 && a.stamps != nullptr};
+#endif
     for (int k = 0; k < 2; ++k) {
         prefetch_pieces<0, 4>(piece_src(pipe, k), piece_dst(pipe, k));
         prefetch_pieces<0, 4>(piece_src(pipe, k) + 4096, piece_dst(pipe, k) + 4096);
@@ -491,12 +531,16 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
         const int64_t pt = pt_raw < a.n_points ? pt_raw : a.n_points - 1;
 
         XT xp0, xp1;
-        float m_pe, m_dd;
+        float m_pe;
         int t_pe;
         {
             f32x16 x0, x1, dd;
-            load_inputs<MODE, true, false>(a, pt, h, x0, x1, dd, &m_dd);   // gamma(dir) itself waits for the view layer
-            m_pe = half_max(tile_absmax(x1, tile_absmax(x0, 0.0f)));
+            load_inputs<MODE, true, false>(a, pt, h, x0, x1, dd);   // gamma(dir) waits for the view layer
+            // The ranges of the encoded inputs are taken over the whole wavefront: wave-uniform, so they live in SGPRs
+            // (the kernel has no vector register to spare: kept per lane, one of them was spilled to scratch, and its
+            // reload - a VMEM load - drained the LDS-DMA weight pipeline with s_waitcnt vmcnt(0) twice per layer).
+            // A wave's points share a ray or two, so the common scale costs the split nothing.
+            m_pe = wave_max(tile_absmax(x1, tile_absmax(x0, 0.0f)));
             t_pe = pick_exponent(m_pe);
             split_tile(xp0, x0, pow2f(t_pe));
             split_tile(xp1, x1, pow2f(t_pe));
@@ -517,7 +561,14 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             pd.floor = is_feature ? -__builtin_inff() : 0.0f;
             float bound = fmaf(tab[1], m_in, tab[2]) * 1.001f;
             // the next layer may concatenate these outputs with inputs that must fit the same scale
-            if (is_feature) bound = fmaxf(bound, m_dd);
+            if (is_feature) {
+                // range of gamma(dir), which the view layer concatenates: re-read from the ray record here (once per
+                // tile) rather than kept in a register through the trunk
+                f32x16 x0, x1, dd;
+                float m_dd;
+                load_inputs<MODE, false, false>(a, pt, h, x0, x1, dd, &m_dd);
+                bound = fmaxf(bound, wave_max(m_dd));
+            }
             else if ((a.skip_in_mask >> (l + 1)) & 1) bound = fmaxf(bound, m_pe);
             pd.t_out = pick_exponent(bound);
             pd.sc = pow2f(pd.t_out);
@@ -632,6 +683,10 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
                 }
             }
         }
+#ifdef NERF_STAMPS
+        STAMP(pipe, 0x7fffff00);
+        pipe.st.on = false;   // first tile only
+#endif
     }   // tile loop
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
