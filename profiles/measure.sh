@@ -1,7 +1,7 @@
 #!/bin/bash
 # round measurement (run on the GPU box: gpurun -- bash profiles/measure.sh): bench lines, rocprofv3 kernel stats and the four PMC passes of the default (fp16-pair) kernel
 set -o pipefail
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/measure; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/measure; rm -rf $O; mkdir -p $O   # (also clear the local gpurun_out/measure first: gpurun merges, it does not mirror)
 cd /tmp; export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
 timeout -k 10 400 python3 $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err && echo bench ok &&
