@@ -235,7 +235,13 @@ __device__ __forceinline__ int pick_exponent(float m) {
 }
 __device__ __forceinline__ float pow2f(int t) { return __builtin_ldexpf(1.0f, t); }
 
-__device__ __forceinline__ float half_max(float m) { return fmaxf(m, __shfl_xor(m, 32)); }
+// max with the partner lane of the other half-wave: v_permlane32_swap on two copies yields (lo, lo) and (hi, hi)
+// - a vector instruction, no trip through the LDS crossbar and no lgkmcnt wait
+__device__ __forceinline__ float half_max(float m) {
+    const unsigned u = __builtin_bit_cast(unsigned, m);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
 // largest value over the wavefront, as a wave-uniform number (lives in an SGPR)
 __device__ __forceinline__ float wave_max(float m) {
 #pragma unroll

@@ -53,6 +53,32 @@ def nets(N, weights_pair):
     return net_c, net_f, q
 
 
+def test_precision_switch_abi(N):
+    """nerf_set_precision / nerf_get_precision (include/nerf_mi355x.h): codes, rejection of anything else, no effect on
+    loaded weights."""
+    import ctypes as C
+    from nerf_projects_amd import _lib
+    lib, ctx = _lib.load(), N.get_context()
+    mine = ctx.get_precision()
+    try:
+        assert lib.nerf_set_precision(ctx.handle, 7) != 0 and b"nerf_set_precision" in lib.nerf_last_error()
+        assert lib.nerf_set_precision(None, 0) != 0
+        assert lib.nerf_get_precision(None) < 0
+        with pytest.raises(ValueError):
+            ctx.set_precision("bf16")
+        net = make_net(N, synthetic.synthetic_state_dict(7))
+        x = gpu(load_golden("mlp_forward")["embedded"])
+        out = {}
+        for p in ("f16x2", "f32", "f16x2"):
+            ctx.set_precision(p)
+            assert ctx.get_precision() == p and lib.nerf_get_precision(ctx.handle) == ctx.PRECISIONS[p]
+            out.setdefault(p, []).append(cpu(net(x)))
+        assert np.array_equal(out["f16x2"][0], out["f16x2"][1])          # deterministic, unaffected by the detour
+        assert np.abs(out["f16x2"][0] - out["f32"][0]).max() <= 1e-5 * np.abs(out["f32"][0]).max()
+    finally:
+        ctx.set_precision(mine)
+
+
 # ---- stage kernels ---------------------------------------------------------------------------
 
 def test_native_library_is_loaded(N):
