@@ -507,3 +507,50 @@ def img2mse(x, y):
 def mse2psnr(x):
     """nerf_helpers.py:12-14."""
     return F32(-10.) * np.log(F32(x)) / np.log(F32(10.))
+
+
+# ---- random-ray batching of train() (nerf/nerf.ipynb cell 19; "train:N" = line N of the cell source) ------------
+def get_rays_np(H, W, K, c2w):
+    """nerf_helpers.py:301-308 (the numpy twin of get_rays the global-batching mode uses)."""
+    i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing='xy')
+    dirs = np.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -np.ones_like(i)], -1)
+    rays_d = np.sum(dirs[..., np.newaxis, :] * c2w[:3, :3], -1)
+    rays_o = np.broadcast_to(c2w[:3, -1], np.shape(rays_d))
+    return rays_o, rays_d
+
+
+def global_ray_batches(images, poses, H, W, K, i_train, N_rand, n_batches, rng):
+    """use_batching mode (train:190-203, 230-242): all rays of the training images, shuffled once with the numpy
+    stream, consumed in consecutive windows. Returns a list of (batch_rays [2,N,3], target_s [N,3]).
+    (The epoch-end ``torch.randperm`` reshuffle is not restated: it needs torch's RNG.)"""
+    rays = np.stack([np.stack(get_rays_np(H, W, K, p), 0) for p in poses[:, :3, :4]], 0)      # [N, ro+rd, H, W, 3]
+    rays_rgb = np.concatenate([rays, images[:, None]], 1)                                     # [N, ro+rd+rgb, H, W, 3]
+    rays_rgb = np.transpose(rays_rgb, [0, 2, 3, 1, 4])
+    rays_rgb = np.stack([rays_rgb[i] for i in i_train], 0)
+    rays_rgb = np.reshape(rays_rgb, [-1, 3, 3]).astype(np.float32)
+    rng.shuffle(rays_rgb)
+    out, i_batch = [], 0
+    for _ in range(n_batches):
+        batch = np.transpose(rays_rgb[i_batch:i_batch + N_rand], [1, 0, 2])
+        out.append((batch[:2], batch[2]))
+        i_batch += N_rand
+    return out
+
+
+def per_image_ray_batch(images, poses, H, W, K, i_train, N_rand, i, precrop_iters, precrop_frac, rng):
+    """no_batching mode (train:243-276): random training image, optional centre crop, N_rand distinct pixels."""
+    img_i = rng.choice(i_train)
+    target = images[img_i]
+    rays_o, rays_d = get_rays(H, W, K, poses[img_i, :3, :4])               # train:252 uses the torch get_rays
+    if i < precrop_iters:
+        dH = int(H // 2 * precrop_frac)
+        dW = int(W // 2 * precrop_frac)
+        rows = np.linspace(H // 2 - dH, H // 2 + dH - 1, 2 * dH, dtype=np.float32)
+        cols = np.linspace(W // 2 - dW, W // 2 + dW - 1, 2 * dW, dtype=np.float32)
+    else:
+        rows, cols = np.linspace(0, H - 1, H, dtype=np.float32), np.linspace(0, W - 1, W, dtype=np.float32)
+    coords = np.stack(np.meshgrid(rows, cols, indexing="ij"), -1).reshape(-1, 2)
+    select_inds = rng.choice(coords.shape[0], size=[N_rand], replace=False)
+    sel = coords[select_inds].astype(np.int64)
+    return (np.stack([rays_o[sel[:, 0], sel[:, 1]], rays_d[sel[:, 0], sel[:, 1]]], 0), target[sel[:, 0], sel[:, 1]],
+            int(img_i), sel)
