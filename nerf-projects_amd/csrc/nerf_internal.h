@@ -173,7 +173,7 @@ struct GemmTN {        // part[slice][Mo, No] = sum_p A[p,Mo]^T B[p,No];  dbp[sl
     float* dbp;
 };
 hipError_t launch_gemm_rows(const GemmRows& g, hipStream_t s);
-hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, float* db, hipStream_t s);
+hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, float* db, int accumulate, hipStream_t s);
 hipError_t launch_embed_train(const float* rays, int ray_ld, const float* z, int64_t P, int S, int Lx, int Lv,
                               float* xcat, int ldx, float* vcat, int ldv, int voff, hipStream_t s);
 hipError_t launch_mse(const float* x, const float* t, int64_t n, float* grad, double* part, float* loss, hipStream_t s);

@@ -155,6 +155,7 @@ struct TnScratch {
     float* dbp;       // [max_slices][256] partial db
     int max_slices;
     int64_t P;        // points of the pass being differentiated
+    int accumulate;   // add to the gradients already there (the second pass through a shared network)
 };
 
 // Slices per GEMM: the grid is slices x ceil(No/128) workgroups at one per CU, so aim at a whole number of
@@ -175,7 +176,7 @@ int grad_linear(const PackedNet& net, const LinearDesc& d, const float* dY, int 
     int64_t pps = (P + n_slices - 1) / n_slices;
     pps = (pps + 31) / 32 * 32;
     GemmTN g{dY, ldy, X, ldx, P, d.out, d.in, pps, sc.part, sc.dbp};
-    HIP_TRY(launch_gemm_tn(g, n_slices, net.train.d_grad + d.w_off, d.in, net.train.d_grad + d.b_off, s));
+    HIP_TRY(launch_gemm_tn(g, n_slices, net.train.d_grad + d.w_off, d.in, net.train.d_grad + d.b_off, sc.accumulate, s));
     return NERF_OK;
 }
 
@@ -215,7 +216,8 @@ int backward_pass(Pass& ps, const TnScratch& sc, hipStream_t s) {
         HIP_TRY(launch_gemm_rows(g1, s));
         // views_linears is never evaluated without viewdirs: its gradient is zero
         const LinearDesc& views = net.linears[a.D];
-        HIP_TRY(hipMemsetAsync(net.train.d_grad + views.w_off, 0, ((size_t)views.out * views.in + views.out) * sizeof(float), s));
+        if (!sc.accumulate)
+            HIP_TRY(hipMemsetAsync(net.train.d_grad + views.w_off, 0, ((size_t)views.out * views.in + views.out) * sizeof(float), s));
     }
     for (int i = a.D - 1; i >= 0; --i) {
         const LinearDesc& d = net.linears[i];
@@ -270,11 +272,9 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
         nfp = &c->nets[r->slot_fine];
     }
     PackedNet& nf = *nfp;
+    // network_fine=None with N_importance > 0 (nerf.ipynb:471: run_fn = network_fn): both passes go through one
+    // network and its gradient is the sum over the passes
     const bool shared = (&nf == &nc) && Si > 0;
-    if (shared) {
-        set_error("training with network_fine=None (one network for both passes) is not supported yet");
-        return NERF_E_INVALID;
-    }
     for (PackedNet* n : {&nc, &nf}) {
         if (n->arch.use_viewdirs && r->ray_stride < 11) {
             set_error("the model uses viewdirs but rays carry only %d columns", r->ray_stride);
@@ -315,7 +315,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     float* g_f = Si ? ar.take((size_t)N * 3) : nullptr;
     double* red = (double*)ar.take(2048);   // 2 x 512 doubles of per-block partials
     float* loss_dev = ar.take(4);
-    TnScratch sc{ar.take(part_floats), ar.take((size_t)n_slices * 256), n_slices, 0};
+    TnScratch sc{ar.take(part_floats), ar.take((size_t)n_slices * 256), n_slices, 0, 0};
 
     Pass pc;
     pc.net = &nc;
@@ -364,6 +364,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
         HIP_TRY(launch_composite_bwd(pf.raw, pf.C, z_f, r->rays + 3, r->ray_stride, r->noise, r->white_bkgd, N, Sf, g_f,
                                      pf.d_raw, s));
         sc.P = Pf;
+        sc.accumulate = shared ? 1 : 0;
         if ((rc = backward_pass(pf, sc, s))) return rc;
         nf.train.grads_valid = true;
     }
@@ -377,7 +378,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
             HIP_TRY(launch_adam(n->d_params, n->train.d_grad, n->train.d_m, n->train.d_v, (int64_t)n->n_params, r->lr,
                                 r->beta1, r->beta2, r->eps, r->step, s));
             if ((rc = refresh_derived(*n, s))) return rc;
-            if (!Si) break;
+            if (!Si || shared) break;
         }
     }
     return NERF_OK;

@@ -308,22 +308,24 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmTN g) {
 
 // dW[m][n] = sum_s part[s][m][n] and db[m] = sum_s dbp[s][m], slices added in order (deterministic)
 __global__ void reduce_slices_kernel(const float* __restrict__ part, const float* __restrict__ dbp, int n_slices,
-                                     int Mo, int No, float* __restrict__ dW, int ldw, float* __restrict__ db) {
+                                     int Mo, int No, float* __restrict__ dW, int ldw, float* __restrict__ db,
+                                     int accumulate) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n_w = (int64_t)Mo * No;
     if (idx < n_w) {
         float s = 0.0f;
         for (int k = 0; k < n_slices; ++k) s += part[(int64_t)k * n_w + idx];
-        dW[(idx / No) * ldw + (idx % No)] = s;
+        float* w = dW + (idx / No) * ldw + (idx % No);
+        *w = accumulate ? *w + s : s;   // second pass through a shared network: .grad accumulates (nerf.ipynb:1270)
     } else if (idx < n_w + Mo && db && dbp) {
         const int m = (int)(idx - n_w);
         float s = 0.0f;
         for (int k = 0; k < n_slices; ++k) s += dbp[(int64_t)k * Mo + m];
-        db[m] = s;
+        db[m] = accumulate ? db[m] + s : s;
     }
 }
 
-hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, float* db, hipStream_t s) {
+hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, float* db, int accumulate, hipStream_t s) {
     if (g.Mo <= 0 || g.No <= 0) return hipSuccess;
     if (g.Mo > 256) return hipErrorInvalidValue;
     static bool raised[64] = {};
@@ -334,7 +336,7 @@ hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, flo
     hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)n_slices, (unsigned)((g.No + 127) / 128)), dim3(512), kTnLds, s, g);
     const int64_t total = (int64_t)g.Mo * g.No + g.Mo;
     hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g.part, g.dbp, n_slices,
-                       g.Mo, g.No, dW, ldw, db);
+                       g.Mo, g.No, dW, ldw, db, accumulate);
     return hipGetLastError();
 }
 

@@ -934,9 +934,8 @@ def train_on_batch(H, W, K, batch_rays, target_s, optimizer, chunk=1024 * 32, nd
     img2mse(rgb, target_s)`` (``+ img2mse(rgb0, target_s)``), ``loss.backward()``, ``optimizer.step()``.
     Pass the same ``render_kwargs_train`` (plus ``near``/``far``) as keyword arguments. Returns
     ``{'loss','img_loss','psnr'[, 'img_loss0','psnr0'], 'rgb'[, 'rgb0']}`` (tensors on the device)."""
-    if not isinstance(network_fn, NeRF) or (N_importance > 0 and not isinstance(network_fine, NeRF)):
-        raise TypeError("train_on_batch needs this package's NeRF models (a distinct network_fine when "
-                        "N_importance > 0)")
+    if not isinstance(network_fn, NeRF) or (network_fine is not None and not isinstance(network_fine, NeRF)):
+        raise TypeError("train_on_batch needs this package's NeRF models")
     ctx = network_fn.ctx
     packed, _ = pack_rays(H, W, K, batch_rays, None, ndc, near, far, use_viewdirs, None, device=ctx.device)
     packed = packed.contiguous()
@@ -949,7 +948,8 @@ def train_on_batch(H, W, K, batch_rays, target_s, optimizer, chunk=1024 * 32, nd
     a = TrainArgs()
     a.rays, a.target, a.n_rays, a.ray_stride = packed.data_ptr(), target.data_ptr(), N, stride
     a.N_samples, a.N_importance = Sc, Si
-    a.slot_coarse, a.slot_fine = network_fn.slot, (network_fine.slot if Si > 0 else -1)
+    # network_fine=None with N_importance > 0: both passes through network_fn (nerf.ipynb:471)
+    a.slot_coarse, a.slot_fine = network_fn.slot, (network_fine.slot if Si > 0 and network_fine is not None else -1)
     a.lindisp, a.white_bkgd = int(bool(lindisp)), int(bool(white_bkgd))
     keep = [packed, target]
     perturb = float(perturb)

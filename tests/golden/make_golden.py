@@ -427,6 +427,38 @@ def gold_train():
     save("train_step", rays=n(rays), target=n(target), **out)
 
 
+def gold_train_variants():
+    """One iteration of the same loop body in the two other configurations create_nerf can produce
+    (nerf.ipynb:887-896): network_fine=None with N_importance > 0 (both passes through ONE network, whose
+    gradient is the sum over the passes) and N_importance = 0 (a single pass, loss = img_loss only)."""
+    g = np.load(os.path.join(HERE, "render_rays_lego.npz"))
+    rays = torch.from_numpy(g["rays"][:32])
+    rs = np.random.RandomState(106)
+    target = torch.from_numpy(rs.uniform(0, 1, size=(32, 3)).astype(np.float32))
+    e_fn, _ = ref_embedder.get_embedder(10, 0)
+    ed_fn, _ = ref_embedder.get_embedder(4, 0)
+    out = {}
+    for tag, n_imp in (("shared", 128), ("coarse", 0)):
+        net_c, _ = ref_pair(0)
+        net_c.train()
+        kw = dict(N_samples=64, N_importance=n_imp, retraw=True, white_bkgd=True, perturb=1.0, raw_noise_std=1.0,
+                  pytest=True)
+        ret = NS["render_rays"](rays, net_c, query_fn(e_fn, ed_fn), network_fine=None, **kw)
+        img_loss = ref_helpers.img2mse(ret["rgb_map"], target)
+        loss = img_loss
+        out[f"{tag}.img_loss"] = n(img_loss)
+        if "rgb0" in ret:
+            img_loss0 = ref_helpers.img2mse(ret["rgb0"], target)
+            loss = loss + img_loss0
+            out[f"{tag}.img_loss0"] = n(img_loss0)
+        loss.backward()
+        for k, p in net_c.named_parameters():
+            gr = n(p.grad).reshape(-1) if p.grad is not None else np.zeros(p.numel(), np.float32)
+            out[f"{tag}.gnorm.{k}"] = np.linalg.norm(gr.astype(np.float64))
+            out[f"{tag}.gsub.{k}"] = gr[::61].copy()
+    save("train_step_variants", rays=n(rays), target=n(target), **out)
+
+
 def gold_llff_pose_math():
     """The pure-numpy pose functions of nerf/load_llff.py, executed from its source (the module itself
     cannot be imported here: it needs imageio). Only function definitions that touch numpy alone are
@@ -474,4 +506,5 @@ if __name__ == "__main__":
     gold_ray_packing()
     gold_metrics()
     gold_train()
+    gold_train_variants()
     gold_llff_pose_math()

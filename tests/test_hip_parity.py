@@ -605,6 +605,38 @@ def test_train_gradients_match_autograd(N, weights_pair):
     assert np.array_equal(net_c.state_dict()["pts_linears.0.weight"].numpy(), weights_pair[0]["pts_linears.0.weight"])
 
 
+@pytest.mark.parametrize("tag,n_imp", [("shared", 128), ("coarse", 0)])
+def test_train_gradients_shared_and_single_network(N, weights_pair, tag, n_imp):
+    """The other two configurations create_nerf can hand to the loop (nerf.ipynb:887-896, :471): network_fine=None with
+    N_importance > 0 - both passes through one network, whose gradient is the SUM over the passes - and N_importance = 0;
+    against the reference's autograd (tests/golden/train_step_variants.npz)."""
+    g = load_golden("train_step_variants")
+    net = make_net(N, weights_pair[0])
+    rays = g["rays"]
+    kw = dict(network_fn=net, network_fine=None, N_samples=64, N_importance=n_imp, white_bkgd=True, perturb=1.0,
+              raw_noise_std=1.0, pytest=True, ndc=False, use_viewdirs=True, near=2., far=6.,
+              network_query_fn=N.make_network_query_fn(N.get_embedder(10, 0)[0], N.get_embedder(4, 0)[0]))
+    opt = N.Adam([net], lr=5e-4)
+    out = N.train_on_batch(800, 800, None, (gpu(rays[:, 0:3]), gpu(rays[:, 3:6])), gpu(g["target"]), opt,
+                           apply_update=False, **kw)
+    assert abs(float(out["img_loss"]) - float(g[f"{tag}.img_loss"])) <= 2e-6
+    if n_imp:
+        assert abs(float(out["img_loss0"]) - float(g[f"{tag}.img_loss0"])) <= 2e-6
+    else:
+        assert "img_loss0" not in out
+    for k, gr in net.grad_dict().items():
+        gr = gr.numpy().reshape(-1)
+        want_norm, want_sub = float(g[f"{tag}.gnorm.{k}"]), g[f"{tag}.gsub.{k}"]
+        tol = 2e-4 if n_imp else 2e-5            # the fine pass inherits the resampling sensitivity
+        assert abs(np.linalg.norm(gr.astype(np.float64)) - want_norm) <= tol * want_norm + 1e-9, k
+        assert np.abs(gr[::61] - want_sub).max() <= 5 * tol * (np.abs(want_sub).max() + 1e-12) + 1e-9, k
+    # and one real step: Adam runs once on the single network
+    out = N.train_on_batch(800, 800, None, (gpu(rays[:, 0:3]), gpu(rays[:, 3:6])), gpu(g["target"]), opt, **kw)
+    assert opt.steps == 1
+    moved = np.abs(net.state_dict()["pts_linears.3.weight"].numpy() - weights_pair[0]["pts_linears.3.weight"]).max()
+    assert 0 < moved <= 1.01 * 5e-4
+
+
 def test_two_adam_steps_match_reference(N, weights_pair):
     g, net_c, net_f, kw, batch_rays, target = _train_setup(N, weights_pair)
     opt = N.Adam([net_c, net_f], lr=5e-4)
