@@ -174,29 +174,19 @@ struct PartTag {
 template <int S, int NSTEP, int VALU_PER_MFMA, class Body>
 __device__ __forceinline__ void run_steps(PipeH& p, Frag4& cur, const f32x4* fr, const f32x4* fr_next, Body& body) {
     if constexpr (S < NSTEP) {
-#ifndef NERF_DMA_POS
-#define NERF_DMA_POS 0
-#endif
-        auto pieces = [&]() {
-#ifndef NERF_ABLATE_DMA
-            constexpr int per = 8 / NSTEP;   // pieces per step
-            if constexpr (S < NSTEP / 2) prefetch_pieces<S * per, (S + 1) * per>(p.g_first, p.l_first);
-            else prefetch_pieces<(S - NSTEP / 2) * per, (S - NSTEP / 2 + 1) * per>(p.g_second, p.l_second);
-#endif
-        };
-        if constexpr (NERF_DMA_POS == 1) {
-            pieces();
-            __builtin_amdgcn_sched_barrier(0);
-        }
         body(StepTag<S>{}, PartTag<0>{}, cur);
         __builtin_amdgcn_sched_barrier(0);
         STAMP(p, (p.c << 8) | (S << 4) | VALU_PER_MFMA);
-        if constexpr (NERF_DMA_POS == 2) pieces();
         body(StepTag<S>{}, PartTag<2>{}, cur);   // before the fragment reads: lds_pair_wait counts on that
         Frag4 nxt = (S + 1 < NSTEP) ? read_frags(fr, (S + 1) * 4) : read_frags(fr_next, 0);
-        // (the LDS-DMA pieces follow the reads: a piece stalls the issuing wave for 60+ cycles wherever it goes -
-        // MI355X_MICROARCH.md - and between the later MFMAs, next to the conversion work, it cost 9 % more)
-        if constexpr (NERF_DMA_POS == 0) pieces();
+        // The step's LDS-DMA pieces follow the reads. A piece stalls the issuing wave for ~60 cycles wherever it goes
+        // (MI355X_MICROARCH.md); tried and measured on one box: before the first MFMA +0.4 %, ahead of the reads +1.8 %,
+        // after the last MFMA +1.2 %, between MFMAs 3 and 4 next to the conversion work +9 %.
+#ifndef NERF_ABLATE_DMA
+        constexpr int per = 8 / NSTEP;   // pieces per step
+        if constexpr (S < NSTEP / 2) prefetch_pieces<S * per, (S + 1) * per>(p.g_first, p.l_first);
+        else prefetch_pieces<(S - NSTEP / 2) * per, (S - NSTEP / 2 + 1) * per>(p.g_second, p.l_second);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         body(StepTag<S>{}, PartTag<1>{}, cur);
         if constexpr (VALU_PER_MFMA > 0) {
@@ -208,10 +198,6 @@ __device__ __forceinline__ void run_steps(PipeH& p, Frag4& cur, const f32x4* fr,
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NERF_DMA_POS == 3) {
-            pieces();
-            __builtin_amdgcn_sched_barrier(0);
-        }
         cur = nxt;
         if constexpr (S == NSTEP / 2 - 1) {
 #if defined(NERF_ABLATE_VMWAIT)
