@@ -82,6 +82,12 @@ void nerf_ctx_destroy(nerf_ctx* ctx);
 #define NERF_PRECISION_F16X2 1
 int nerf_set_precision(nerf_ctx* ctx, int precision);
 int nerf_get_precision(nerf_ctx* ctx);
+/* NERF_PRECISION_F16X2 chooses a layer's per-point output scale from an a-priori bound (largest row sum of |W| x
+ * largest |input| + largest |bias|). A bound 2^12 or more above a point's real outputs starts to cost low-order
+ * bits; each such (wavefront, layer) occurrence is counted, never silent. Synchronises the device; `reset` zeroes the
+ * counter. 0 on every network trained or initialised like a NeRF; non-zero means: use NERF_PRECISION_F32 for these
+ * weights (rows of large weights that cancel). */
+int nerf_precision_status(nerf_ctx* ctx, int64_t* loose_bound_events, int reset);
 
 /* Weights ---------------------------------------------------------------------------
  * Replaces NeRF.__init__ + load_state_dict (nerf/nerf.py:9-55; checkpoint reload at

@@ -34,6 +34,7 @@ int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net, int mode, hipStream
     a.stream_h2 = net.d_stream_h2;
     a.descale = net.d_descale;
     a.gain = net.d_gain;
+    a.loose = c->d_loose;
     a.bias = net.d_bias;
     a.n_chunks = net.n_chunks;
     a.n_bias_tiles = net.n_bias_tiles;
@@ -200,6 +201,16 @@ int nerf_ctx_create(int device, nerf_ctx** out) {
     nerf_ctx* c = new (std::nothrow) nerf_ctx();
     if (!c) return NERF_E_NOMEM;
     c->device = device;
+    {
+        DeviceGuard g(device);
+        hipError_t e2 = hipMalloc((void**)&c->d_loose, sizeof(unsigned));
+        if (e2 == hipSuccess) e2 = hipMemset(c->d_loose, 0, sizeof(unsigned));
+        if (e2 != hipSuccess) {
+            set_error("nerf_ctx_create: device allocation failed: %s", hipGetErrorString(e2));
+            delete c;
+            return NERF_E_HIP;
+        }
+    }
     *out = c;
     return NERF_OK;
 }
@@ -211,6 +222,7 @@ void nerf_ctx_destroy(nerf_ctx* c) {
     for (auto& n : c->nets) free_net(n);
     if (c->ws) (void)hipFree(c->ws);
     if (c->frame_rays) (void)hipFree(c->frame_rays);
+    if (c->d_loose) (void)hipFree(c->d_loose);
     for (auto& p : c->events) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -664,5 +676,19 @@ int nerf_profile_read(nerf_ctx* c, double* mlp_ms, int64_t* launches, int64_t* p
 }
 
 int64_t nerf_workspace_bytes(nerf_ctx* c) { return c ? (int64_t)c->ws_bytes : 0; }
+
+int nerf_precision_status(nerf_ctx* c, int64_t* loose_bound_events, int reset) {
+    if (!c || !loose_bound_events) {
+        set_error("nerf_precision_status: NULL argument");
+        return NERF_E_INVALID;
+    }
+    DeviceGuard g(c->device);
+    unsigned v = 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&v, c->d_loose, sizeof(v), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(c->d_loose, 0, sizeof(v)));
+    *loose_bound_events = (int64_t)v;
+    return NERF_OK;
+}
 
 }  // extern "C"

@@ -20,6 +20,7 @@ struct nerf_ctx {
     int device = 0;
     int precision = NERF_PRECISION_F16X2;   // arithmetic of the fused MLP kernel (nerf_set_precision)
     nerf::PackedNet nets[NERF_NUM_SLOTS];
+    unsigned* d_loose = nullptr;   // see nerf_precision_status
     char* ws = nullptr;          // workspace arena
     size_t ws_bytes = 0;
     float* frame_rays = nullptr;   // ray record of the chunk being rendered by nerf_render_frame

@@ -583,7 +583,13 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             pd.m = 0.0f;
         };
         // all 8 tiles of the pending layer are converted: its true output range
-        auto close_pending = [&]() { m_prev = half_max(pd.m); };
+        auto close_pending = [&]() {
+            m_prev = half_max(pd.m);
+            // the scale was chosen for a bound of 2^(10 - t_out); outputs 2^12 and more below it have begun to lose
+            // low-half bits (see Pending). Counted, never silent: nerf_precision_status.
+            const int slack = 10 - pd.t_out - __builtin_amdgcn_frexp_expf(m_prev);
+            if (m_prev > 0.0f && slack >= 12 && pd.t_out > -60 && a.loose) atomicAdd(a.loose, 1u);
+        };
 
         // layer 0: gamma(xyz) -> W (nerf.py:70-73)
         chunk_ktile8<-1, true>(pipe, cur, accA, xp0, hid, accB, pd);

@@ -91,6 +91,7 @@ struct MlpLaunch {
     const uint32_t* stream_h2;   // NERF_PRECISION_F16X2 only
     const float* descale;
     const float* gain;
+    unsigned* loose;             // counter of (wave, layer) events where the a-priori output bound was >= 2^12 x too wide
     unsigned long long* stamps;   // -DNERF_STAMPS builds only: s_memtime samples of one wave (profiles/microbench/stamps.py)
     const float* bias;
     int n_chunks;

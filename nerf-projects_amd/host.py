@@ -56,6 +56,13 @@ class Context:
             raise ValueError(f"precision {name!r}: expected one of {sorted(self.PRECISIONS)}")
         check(self.lib.nerf_set_precision(self.handle, self.PRECISIONS[name]))
 
+    def precision_status(self, reset=True):
+        """Number of (wavefront, layer) events since the last reset in which the fp16-pair kernel's a-priori output
+        bound was >= 2^12 too wide (0 for NeRF-like weights; otherwise prefer ``set_precision("f32")``). Synchronises."""
+        n = C.c_int64()
+        check(self.lib.nerf_precision_status(self.handle, C.byref(n), int(bool(reset))))
+        return n.value
+
     def get_precision(self):
         code = self.lib.nerf_get_precision(self.handle)
         return {v: k for k, v in self.PRECISIONS.items()}[code]

@@ -79,6 +79,35 @@ def test_precision_switch_abi(N):
         ctx.set_precision(mine)
 
 
+def test_loose_bound_is_counted_not_silent(N):
+    """nerf_precision_status: zero on ordinary weights; weights whose rows are large but cancel (so that the a-priori
+    bound of the fp16-pair kernel overshoots the real outputs by > 2^12) are reported."""
+    ctx = N.get_context()
+    mine = ctx.get_precision()
+    try:
+        ctx.set_precision("f16x2")
+        x = gpu(load_golden("mlp_forward")["embedded"])
+        sd = dict(synthetic.synthetic_state_dict(7))
+        net = make_net(N, sd)
+        ctx.precision_status(reset=True)
+        net(x)
+        assert ctx.precision_status() == 0
+        w = np.asarray(sd["pts_linears.2.weight"]).copy()
+        big = np.float32(3e4) * np.ones((256, 128), np.float32)
+        w[:, :128] += big                      # + c on inputs k ...
+        w[:, 128:] -= big                      # ... - c on inputs k + 128, fed the SAME activations below
+        sd["pts_linears.2.weight"] = w
+        w1, b1 = np.asarray(sd["pts_linears.1.weight"]).copy(), np.asarray(sd["pts_linears.1.bias"]).copy()
+        w1[128:], b1[128:] = w1[:128], b1[:128]
+        sd["pts_linears.1.weight"], sd["pts_linears.1.bias"] = w1, b1
+        net2 = make_net(N, sd)
+        net2(x)
+        assert ctx.precision_status() > 0
+        assert ctx.precision_status() == 0      # reset by the read
+    finally:
+        ctx.set_precision(mine)
+
+
 # ---- stage kernels ---------------------------------------------------------------------------
 
 def test_native_library_is_loaded(N):
