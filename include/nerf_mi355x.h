@@ -285,6 +285,12 @@ int nerf_train_step(nerf_ctx* ctx, const nerf_train_args* args);
 /* Current master weights / last gradients of a slot, copied to host tensors in nerf_load_weights order. */
 int nerf_get_weights(nerf_ctx* ctx, int slot, float* const* tensors /*[host]*/, int n_tensors);
 int nerf_get_gradients(nerf_ctx* ctx, int slot, float* const* tensors /*[host]*/, int n_tensors);
+/* torch.optim.Adam's per-parameter state (exp_avg, exp_avg_sq) of a slot, host tensors in nerf_load_weights order:
+ * the 'optimizer_state_dict' of the reference's checkpoints (nerf.ipynb:1290-1299; reloaded at :925-932). */
+int nerf_get_adam_state(nerf_ctx* ctx, int slot, float* const* exp_avg /*[host]*/, float* const* exp_avg_sq /*[host]*/,
+                        int n_tensors);
+int nerf_set_adam_state(nerf_ctx* ctx, int slot, const float* const* exp_avg /*[host]*/,
+                        const float* const* exp_avg_sq /*[host]*/, int n_tensors);
 
 /* Measurement hooks ------------------------------------------------------------------
  * Accumulated device time of the dominant kernel (the fused encode+MLP kernel),

@@ -18,7 +18,7 @@ EXPORTS = (
     "nerf_raw2outputs", "nerf_sample_pdf", "nerf_render_rays", "nerf_profile_enable", "nerf_profile_read",
     "nerf_workspace_bytes", "nerf_generate_rays", "nerf_image_metrics", "nerf_train_step", "nerf_get_weights",
     "nerf_get_gradients", "nerf_stratified_z", "nerf_resample", "nerf_render_frame", "nerf_set_precision",
-    "nerf_get_precision", "nerf_precision_status",
+    "nerf_get_precision", "nerf_precision_status", "nerf_get_adam_state", "nerf_set_adam_state",
 )
 
 
@@ -136,6 +136,10 @@ def load():
     lib.nerf_set_precision.argtypes = [vp, i32]
     lib.nerf_get_precision.restype = i32
     lib.nerf_get_precision.argtypes = [vp]
+    lib.nerf_get_adam_state.restype = i32
+    lib.nerf_get_adam_state.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), i32]
+    lib.nerf_set_adam_state.restype = i32
+    lib.nerf_set_adam_state.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), i32]
     lib.nerf_precision_status.restype = i32
     lib.nerf_precision_status.argtypes = [vp, C.POINTER(i64), i32]
     _lib = lib

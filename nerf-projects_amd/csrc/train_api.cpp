@@ -419,4 +419,50 @@ int nerf_get_gradients(nerf_ctx* c, int slot, float* const* tensors, int n_tenso
     return copy_flat(c, slot, g, tensors, n_tensors, "nerf_get_gradients");
 }
 
+/* torch.optim.Adam's per-parameter state (exp_avg, exp_avg_sq; the step count is the caller's), so that the
+ * optimizer_state_dict of a checkpoint (nerf.ipynb:1290-1299, reloaded at :925-932) survives a round trip. */
+int nerf_get_adam_state(nerf_ctx* c, int slot, float* const* exp_avg, float* const* exp_avg_sq, int n_tensors) {
+    const float *m = nullptr, *v = nullptr;
+    if (c && slot >= 0 && slot < NERF_NUM_SLOTS && c->nets[slot].train.ready) {
+        m = c->nets[slot].train.d_m;
+        v = c->nets[slot].train.d_v;
+    }
+    int rc = copy_flat(c, slot, m, exp_avg, n_tensors, "nerf_get_adam_state");
+    if (rc == NERF_OK) rc = copy_flat(c, slot, v, exp_avg_sq, n_tensors, "nerf_get_adam_state");
+    return rc;
+}
+
+int nerf_set_adam_state(nerf_ctx* c, int slot, const float* const* exp_avg, const float* const* exp_avg_sq, int n_tensors) {
+    if (!c || !exp_avg || !exp_avg_sq || slot < 0 || slot >= NERF_NUM_SLOTS || !c->nets[slot].loaded) {
+        set_error("nerf_set_adam_state: invalid slot or NULL argument");
+        return NERF_E_INVALID;
+    }
+    PackedNet& net = c->nets[slot];
+    if (n_tensors != (int)net.linears.size() * 2) {
+        set_error("nerf_set_adam_state: expected %d tensors, got %d", (int)net.linears.size() * 2, n_tensors);
+        return NERF_E_INVALID;
+    }
+    DeviceGuard guard(c->device);
+    const bool fresh = !net.train.ready;
+    int rc = ensure_train_state(c, net);
+    if (rc != NERF_OK) return rc;
+    if (fresh && (rc = refresh_derived(net, nullptr))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    for (size_t k = 0; k < net.linears.size(); ++k) {
+        const LinearDesc& d = net.linears[k];
+        const size_t nw = (size_t)d.out * d.in * sizeof(float), nb = (size_t)d.out * sizeof(float);
+        for (int which = 0; which < 2; ++which) {
+            const float* const* src = which ? exp_avg_sq : exp_avg;
+            float* dst = which ? net.train.d_v : net.train.d_m;
+            if (!src[2 * k] || !src[2 * k + 1]) {
+                set_error("nerf_set_adam_state: tensor %zu is NULL", 2 * k);
+                return NERF_E_INVALID;
+            }
+            HIP_TRY(hipMemcpy(dst + d.w_off, src[2 * k], nw, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(dst + d.b_off, src[2 * k + 1], nb, hipMemcpyHostToDevice));
+        }
+    }
+    return NERF_OK;
+}
+
 }  // extern "C"

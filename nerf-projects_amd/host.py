@@ -222,6 +222,27 @@ class NeRF:
         """Gradients of the last training step, keyed like the state dict (``param.grad``)."""
         return {k: torch.from_numpy(v) for k, v in self._read_flat(self.ctx.lib.nerf_get_gradients).items()}
 
+    def adam_state(self):
+        """(exp_avg, exp_avg_sq) of this model's Adam state, each keyed like the state dict."""
+        keys = self.state_dict_keys()
+        m = [np.empty(self._expected_shape(k), dtype=np.float32) for k in keys]
+        v = [np.empty(self._expected_shape(k), dtype=np.float32) for k in keys]
+        pm = (C.c_void_p * len(m))(*[a.ctypes.data for a in m])
+        pv = (C.c_void_p * len(v))(*[a.ctypes.data for a in v])
+        check(self.ctx.lib.nerf_get_adam_state(self.ctx.handle, self.slot, pm, pv, len(m)))
+        return dict(zip(keys, m)), dict(zip(keys, v))
+
+    def load_adam_state(self, exp_avg, exp_avg_sq):
+        """Inverse of :meth:`adam_state`; the sequences are in state-dict order."""
+        keys = self.state_dict_keys()
+        m = [np.ascontiguousarray(np.asarray(a, dtype=np.float32)).reshape(self._expected_shape(k)) for k, a in zip(keys, exp_avg)]
+        v = [np.ascontiguousarray(np.asarray(a, dtype=np.float32)).reshape(self._expected_shape(k)) for k, a in zip(keys, exp_avg_sq)]
+        if len(m) != len(keys) or len(v) != len(keys):
+            raise ValueError(f"expected {len(keys)} tensors per moment")
+        pm = (C.c_void_p * len(m))(*[a.ctypes.data for a in m])
+        pv = (C.c_void_p * len(v))(*[a.ctypes.data for a in v])
+        check(self.ctx.lib.nerf_set_adam_state(self.ctx.handle, self.slot, pm, pv, len(m)))
+
     def load_weights_from_keras(self, weights):
         """nerf/nerf.py:113-146: weights of the original TensorFlow NeRF as a flat list
         ``[kernel, bias] * D, feature, views, rgb, alpha`` with Keras ``[in, out]`` kernels."""
@@ -857,9 +878,9 @@ def load_checkpoint(path):
 
 
 def create_nerf(args, device=None):
-    """``create_nerf`` (nerf.ipynb:876-960) for rendering: embedders, coarse/fine models, the query
-    function, checkpoint reload and the train/test render kwargs. Training state (``grad_vars``,
-    ``optimizer``) is out of this build's scope and returned as ``None``."""
+    """``create_nerf`` (nerf.ipynb:876-960): embedders, coarse/fine models, the query function, the optimizer,
+    checkpoint reload (weights, optimizer state, ``global_step``) and the train/test render kwargs. ``grad_vars`` is the
+    list of models (their parameters live on the device)."""
     import os
     embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
     input_ch_views, embeddirs_fn = 0, None
@@ -874,6 +895,8 @@ def create_nerf(args, device=None):
         model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch,
                           skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs, device=device)
     network_query_fn = make_network_query_fn(embed_fn, embeddirs_fn, args.netchunk)
+    grad_vars = [model] + ([model_fine] if model_fine is not None else [])
+    optimizer = Adam(grad_vars, lr=getattr(args, "lrate", 5e-4), betas=(0.9, 0.999))     # nerf.ipynb:905
     start = 0
     ckpt_dir = os.path.join(args.basedir, args.expname, "checkpoints")
     ft_path = getattr(args, "ft_path", None)
@@ -890,6 +913,8 @@ def create_nerf(args, device=None):
         model.load_state_dict(ckpt['network_fn_state_dict'])
         if model_fine is not None:
             model_fine.load_state_dict(ckpt['network_fine_state_dict'])
+        if ckpt.get('optimizer_state_dict'):
+            optimizer.load_state_dict(ckpt['optimizer_state_dict'])                     # nerf.ipynb:925
     render_kwargs_train = {
         'network_query_fn': network_query_fn, 'perturb': args.perturb, 'N_importance': args.N_importance,
         'network_fine': model_fine, 'N_samples': args.N_samples, 'network_fn': model,
@@ -902,7 +927,7 @@ def create_nerf(args, device=None):
     render_kwargs_test = dict(render_kwargs_train)
     render_kwargs_test['perturb'] = False
     render_kwargs_test['raw_noise_std'] = 0.
-    return render_kwargs_train, render_kwargs_test, start, None, None
+    return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer
 
 
 # ----------------------------------------------------------------------------------------------
@@ -926,10 +951,55 @@ class Adam:
         pass                      # gradients are overwritten by every backward pass
 
     def state_dict(self):
-        return {'steps': self.steps, 'param_groups': [dict(g) for g in self.param_groups]}
+        """``torch.optim.Adam.state_dict()`` layout over ``list(model.parameters()) + list(model_fine.parameters())``
+        (nerf.ipynb:903-905), so the file written at nerf.ipynb:1290-1299 and this one are interchangeable: ``state[i]``
+        = ``{'step', 'exp_avg', 'exp_avg_sq'}`` per parameter, in state-dict order model after model."""
+        g = self.param_groups[0]
+        state, idx = {}, 0
+        for m in self.models:
+            if self.steps > 0:
+                em, ev = m.adam_state()
+                for k in m.state_dict_keys():
+                    state[idx] = {'step': torch.tensor(float(self.steps)), 'exp_avg': torch.from_numpy(em[k]),
+                                  'exp_avg_sq': torch.from_numpy(ev[k])}
+                    idx += 1
+            else:
+                idx += len(m.state_dict_keys())
+        group = {'lr': g['lr'], 'betas': tuple(g['betas']), 'eps': g['eps'], 'weight_decay': 0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'decoupled_weight_decay': False, 'params': list(range(idx))}
+        return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
-        self.steps = int(sd.get('steps', 0))
+        """Accepts the layout above (i.e. the reference's ``ckpt['optimizer_state_dict']``, nerf.ipynb:925-932)."""
+        if 'param_groups' in sd and sd['param_groups']:
+            g = sd['param_groups'][0]
+            self.param_groups[0].update({k: g[k] for k in ('lr', 'betas', 'eps') if k in g})
+            self.param_groups[0]['betas'] = tuple(self.param_groups[0]['betas'])
+        state = sd.get('state', {})
+        if not state:
+            self.steps = int(sd.get('steps', 0))
+            return
+        idx, steps = 0, 0
+        for m in self.models:
+            keys = m.state_dict_keys()
+            entries = [state.get(idx + j) for j in range(len(keys))]
+            idx += len(keys)
+            if any(e is None for e in entries):
+                raise ValueError("optimizer state does not cover every parameter of the models")
+            m.load_adam_state([e['exp_avg'].detach().cpu().numpy() for e in entries],
+                              [e['exp_avg_sq'].detach().cpu().numpy() for e in entries])
+            steps = int(float(entries[0]['step']))
+        self.steps = steps
+
+
+def save_checkpoint(path, global_step, network_fn, network_fine, optimizer):
+    """The file the reference writes every ``i_weights`` iterations (nerf.ipynb:1290-1299) and reloads in
+    ``create_nerf`` (:925-935)."""
+    torch.save({'global_step': int(global_step),
+                'network_fn_state_dict': network_fn.state_dict(),
+                'network_fine_state_dict': network_fine.state_dict() if network_fine is not None else None,
+                'optimizer_state_dict': optimizer.state_dict()}, path)
 
 
 def train_on_batch(H, W, K, batch_rays, target_s, optimizer, chunk=1024 * 32, ndc=True, near=0., far=1.,

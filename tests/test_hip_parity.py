@@ -510,6 +510,7 @@ class _Args:
     dataset_type, no_ndc = 'blender', False
     ft_path, no_reload = None, False
     expname = 'exp'
+    lrate = 5e-4
 
 
 def test_create_nerf_checkpoint_and_render_path(N, O, weights_pair, tmp_path):
@@ -524,7 +525,7 @@ def test_create_nerf_checkpoint_and_render_path(N, O, weights_pair, tmp_path):
                 'network_fine_state_dict': {k: torch.from_numpy(v) for k, v in sd_f.items()},
                 'optimizer_state_dict': {}}, str(ck / "001234.tar"))
     train_kw, test_kw, start, grad_vars, optimizer = N.create_nerf(args)
-    assert start == 1234 and grad_vars is None and optimizer is None
+    assert start == 1234 and len(grad_vars) == 2 and optimizer.steps == 0 and optimizer.param_groups[0]['lr'] == args.lrate
     assert test_kw['perturb'] is False and test_kw['raw_noise_std'] == 0. and test_kw['ndc'] is False
     assert train_kw['raw_noise_std'] == '1e0' and train_kw['network_fine'] is not None
     g = load_golden("render_small")
@@ -696,6 +697,50 @@ def test_two_adam_steps_match_reference(N, weights_pair):
                          network_fine=make_net(N, weights_pair[1]), white_bkgd=True)
     assert np.abs(cpu(ret["rgb0"]) - cpu(ret0["rgb0"])).max() > 1e-4
     assert torch.isfinite(ret["rgb_map"]).all()
+
+
+def test_checkpoint_round_trip_with_optimizer_state(N, weights_pair, tmp_path):
+    """Two training steps, save_checkpoint (the file of nerf.ipynb:1290-1299), reload through create_nerf: weights, step
+    count and Adam moments come back; the moments agree with torch.optim.Adam's after the same two steps
+    (tests/golden/train_step_adam.npz), and the state dict loads into a real torch.optim.Adam."""
+    g, net_c, net_f, kw, batch_rays, target = _train_setup(N, weights_pair)
+    ga = load_golden("train_step_adam")
+    opt = N.Adam([net_c, net_f], lr=5e-4)
+    for _ in range(2):
+        N.train_on_batch(800, 800, None, batch_rays, target, opt, **kw)
+    sd = opt.state_dict()
+    assert len(sd["state"]) == int(ga["n_params"]) == 48 and float(sd["state"][0]["step"]) == float(ga["step"]) == 2.0
+    assert sorted(sd["param_groups"][0].keys()) == [str(k) for k in ga["group_keys"]]
+    for i in range(48):
+        for name in ("exp_avg", "exp_avg_sq"):
+            got, want = sd["state"][i][name].numpy().reshape(-1)[::61], ga[f"{name}.{i}"]
+            # the fine network (i >= 24) inherits the resampling sensitivity of its second forward pass
+            tol = (1e-4 if i < 24 else 2e-3) * (np.abs(want).max() + 1e-30)
+            assert np.abs(got - want).max() <= tol, (name, i)
+    # torch accepts the layout
+    shapes = [tuple(v.shape) for m in (net_c, net_f) for v in m.state_dict().values()]
+    t_opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(s)) for s in shapes], lr=1e-3)
+    t_opt.load_state_dict(sd)
+    assert float(t_opt.state_dict()["state"][5]["step"]) == 2.0
+    # file round trip through create_nerf
+    args = _Args()
+    args.basedir, args.expname = str(tmp_path), "exp"
+    (tmp_path / "exp" / "checkpoints").mkdir(parents=True)
+    N.save_checkpoint(str(tmp_path / "exp" / "checkpoints" / "000002.tar"), 2, net_c, net_f, opt)
+    train_kw, _, start, grad_vars, opt2 = N.create_nerf(args)
+    assert start == 2 and opt2.steps == 2
+    for a, b in ((net_c, grad_vars[0]), (net_f, grad_vars[1])):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert all(np.array_equal(sa[k].numpy(), sb[k].numpy()) for k in sa)
+        (ma, va), (mb, vb) = a.adam_state(), b.adam_state()
+        assert all(np.array_equal(ma[k], mb[k]) and np.array_equal(va[k], vb[k]) for k in ma)
+    # resumed and original optimizers take the same third step
+    kw2 = dict(kw, network_fn=grad_vars[0], network_fine=grad_vars[1])
+    o1 = N.train_on_batch(800, 800, None, batch_rays, target, opt, **kw)
+    o2 = N.train_on_batch(800, 800, None, batch_rays, target, opt2, **kw2)
+    assert float(o1["loss"]) == float(o2["loss"])
+    w1, w2 = net_c.state_dict()["pts_linears.5.weight"].numpy(), grad_vars[0].state_dict()["pts_linears.5.weight"].numpy()
+    assert np.array_equal(w1, w2)
 
 
 # ---- further configurations of the reference's YAMLs and edge shapes --------------------------------
