@@ -43,16 +43,15 @@ __device__ __forceinline__ F16 frag_at(const float* tile, int row, int h) {
     for (int q = 0; q < 4; ++q) f.q[q] = *(const f32x4*)&tile[row * kLd + 16 * h + 4 * q];
     return f;
 }
+template <int LO, int HI>
 __device__ __forceinline__ void mma_frag(f32x16& acc, const F16& a, const F16& b) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) acc = mfma32(a.q[t >> 2][t & 3], b.q[t >> 2][t & 3], acc);
+    for (int t = LO; t < HI; ++t) acc = mfma32(a.q[t >> 2][t & 3], b.q[t >> 2][t & 3], acc);
 }
-#define SCHED_FRAG_STEP()                                     \
-    do {                                                      \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);    \
-        __builtin_amdgcn_sched_group_barrier(0x008, 15, 0);   \
-    } while (0)
+// The order of a step is pinned with scheduling fences: its first MFMA, the four reads of the next step's fragment
+// into a second register set, then the other 15 MFMAs. Left to itself hipcc reads into the registers the MFMAs still
+// use, i.e. after them, and waits for the first quad at the head of every step.
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // ---------------------------------------------------------------------------------------------
 // C[M,N] = A[M,K] * B[K,N]      (N <= 256, any K; one workgroup = 128 rows x all N columns)
@@ -117,14 +116,16 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmRows g) {
             const float* bs = Bs + (kt & 1) * 256 * kLd;
             const F16 a = frag_at(as, 32 * wave + j, h);
             F16 cur = frag_at(bs, j, h);
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 if (c < n_ct) {
+                    mma_frag<0, 1>(acc[c], a, cur);
+                    FENCE();
                     F16 nxt = cur;
                     if (c + 1 < n_ct) nxt = frag_at(bs, 32 * (c + 1) + j, h);
-                    mma_frag(acc[c], a, cur);
-                    SCHED_FRAG_STEP();
+                    FENCE();
+                    mma_frag<1, 16>(acc[c], a, cur);
+                    FENCE();
                     cur = nxt;
                 }
             }
@@ -268,15 +269,16 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmTN g) {
             const float* bs = Bs + (t & 1) * 128 * kLd;
             const F16 a0 = frag_at(as, 32 * mt0 + j, h), a1 = frag_at(as, 32 * mt1 + j, h);
             F16 cur = frag_at(bs, j, h);
-            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+                mma_frag<0, 1>(acc[0][c], a0, cur);
+                FENCE();
                 F16 nxt = cur;
                 if (c + 1 < 4) nxt = frag_at(bs, 32 * (c + 1) + j, h);
-                mma_frag(acc[0][c], a0, cur);
-                SCHED_FRAG_STEP();
-                mma_frag(acc[1][c], a1, cur);
-                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                FENCE();
+                mma_frag<1, 16>(acc[0][c], a0, cur);
+                mma_frag<0, 16>(acc[1][c], a1, cur);
+                FENCE();
                 cur = nxt;
             }
         } else if (t + 1 < n_pt) {
