@@ -9,17 +9,18 @@
 //   * every fp32 operand v is carried as two fp16 numbers, v ~= hi + lo with hi = rn16(v) and
 //     lo = rn16(v - hi): |v - hi - lo| <= 2^-24 |v|, what fp32 itself keeps. A product W*x is the three
 //     v_mfma_f32_32x32x16_f16 terms W_lo*x_hi + W_hi*x_lo + W_hi*x_hi (fp16 x fp16 is exact in the fp32
-//     accumulator; the dropped W_lo*x_lo is below 2^-24 relative). Measured on random 256-long dot products the result
-//     is within 0.5-1.0 eps(fp32) rms of the exact value, against 0.4-0.5 eps for the fp32 MFMA chain
-//     (profiles/microbench/mfma_bf16_split.hip): the stage tolerances of the fp32 path hold.
+//     accumulator; the dropped W_lo*x_lo is below 2^-24 relative). Against an fp64 evaluation of the 8x256 network
+//     the result is as close as the fp32 MFMA chain's, or closer (tests: test_mlp_precisions_vs_fp64;
+//     profiles/microbench/mfma_bf16_split.hip has the single-layer numbers and the schemes that were ruled out).
 //   * fp16 has 5 exponent bits, so both operands are kept in range by exact power-of-two scalings:
 //     each layer's weights by one factor chosen from the layer's largest |w| (convert kernel below; the
-//     inverse factor travels in `descale`), each POINT's activation vector by its own factor chosen
-//     from that point's largest activation after every layer. A point is a column of the MFMA, so its
-//     factor is a per-lane multiplier folded into the fma that adds the bias: no activation of any
-//     magnitude overflows, and the low pieces never fall into the subnormal range.
-//   * the bias is added, ReLU applied and the next scale chosen in fp32 on the accumulator values;
-//     the alpha and rgb heads stay fp32 VALU dot products on those values.
+//     inverse factor travels in `descale`), each POINT's activation vector by its own factor, chosen
+//     after every layer from an a-priori bound of that point's outputs (see Pending). A point is a
+//     column of the MFMA, so its factor is a per-lane multiplier folded into the fma that adds the
+//     bias: no activation of any magnitude overflows.
+//   * the bias is added, ReLU applied and the operands re-split in fp32 on the accumulator values, one
+//     output tile per chunk of the NEXT layer, in the shadow of its MFMAs; alpha_linear is one more MFMA
+//     tile, rgb_linear an fp32 dot product on the last layer's values.
 //
 // Cost per layer and wave: 384 MFMAs of 32 cycles against 1024 of 64.
 #include "mlp_inputs.h"
