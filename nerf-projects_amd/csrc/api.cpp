@@ -158,7 +158,7 @@ const PackedNet* get_net(nerf_ctx* c, int slot) {
 extern "C" {
 
 const char* nerf_last_error(void) { return g_err; }
-const char* nerf_version(void) { return "nerf_mi355x 0.1 (gfx950, fp32 MFMA)"; }
+const char* nerf_version(void) { return "nerf_mi355x 0.2 (gfx950; MLP arithmetic: fp16-pair MFMA [default] or fp32 MFMA)"; }
 
 int nerf_device_count(void) {
     int n = 0;
