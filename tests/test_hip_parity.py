@@ -743,6 +743,30 @@ def test_checkpoint_round_trip_with_optimizer_state(N, weights_pair, tmp_path):
     assert np.array_equal(w1, w2)
 
 
+def test_ray_batcher_feeds_training_on_the_device(N, weights_pair):
+    """RayBatcher with its tensors on the GPU (both modes) hands train_on_batch what the loop head of train() would."""
+    rs = np.random.RandomState(3)
+    H = W = 24
+    images = rs.rand(3, H, W, 3).astype(np.float32)
+    poses = np.stack([np.asarray(synthetic.pose_spherical(30.0 * k, -30.0, 4.0), np.float32) for k in range(3)])
+    focal = .5 * W / np.tan(.5 * 0.6911112070083618)
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]], np.float32)
+    net_c, net_f = make_net(N, weights_pair[0]), make_net(N, weights_pair[1])
+    opt = N.Adam([net_c, net_f], lr=5e-4)
+    kw = dict(network_fn=net_c, network_fine=net_f, N_samples=16, N_importance=16, white_bkgd=True, perturb=1.0,
+              raw_noise_std=0.0, ndc=False, use_viewdirs=True, near=2., far=6.,
+              network_query_fn=N.make_network_query_fn(N.get_embedder(10, 0)[0], N.get_embedder(4, 0)[0]))
+    for use_batching in (True, False):
+        b = N.RayBatcher(images, poses, H, W, K, [0, 1, 2], 64, use_batching=use_batching, precrop_iters=1,
+                         precrop_frac=0.5, device="cuda", rng=np.random.RandomState(1))
+        for i in range(2):
+            batch_rays, target_s = b.next(i)
+            assert batch_rays.is_cuda and batch_rays.shape == (2, 64, 3) and target_s.shape == (64, 3)
+            out = N.train_on_batch(H, W, K, batch_rays, target_s, opt, **kw)
+            assert torch.isfinite(out["loss"]) and float(out["loss"]) > 0
+    assert opt.steps == 4
+
+
 # ---- further configurations of the reference's YAMLs and edge shapes --------------------------------
 
 def test_ship_config_96_192(N, O, nets):
