@@ -17,7 +17,8 @@ The roofline object prices the fused encode+MLP kernel with HIP events recorded 
 inside the timed region. Default arithmetic ("f16x2"): every fp32 operand is carried exactly as two fp16
 halves and every product costs three v_mfma_f32_32x32x16_f16, so the algorithmic FLOP rate is priced
 against one third of the dense fp16 MFMA peak (2516.6 / 3 = 838.9 TFLOP/s, MI355X_MICROARCH.md);
-`--precision f32` runs the v_mfma_f32_32x32x2_f32 kernel, priced against 157.3 TFLOP/s. The cpu_baseline object times the CPU oracle (numpy port, oracle/nerf_oracle.py) on
+`--precision f32` runs the v_mfma_f32_32x32x2_f32 kernel, priced against 157.3 TFLOP/s. After the timed region the
+other mode renders two frames of the same rays and its figures are reported in `other_precision`. The cpu_baseline object times the CPU oracle (numpy port, oracle/nerf_oracle.py) on
 a bounded sample of the same rays; it is reported next to the GPU number, never used by it.
 """
 import argparse
@@ -56,6 +57,8 @@ def parse():
                    help="arithmetic of the fused MLP kernel (default: the library's, f16x2)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-other-precision", action="store_true",
+                   help="skip the short run in the other arithmetic mode that is reported next to the result")
     p.add_argument("--force-collective", action="store_true",
                    help="under torch.distributed.run with one rank: still create the RCCL group and gather")
     return p.parse_args()
@@ -181,6 +184,35 @@ def main():
     else:
         mlp_ms_sum, pts_sum, launches_sum = mlp_ms, float(mlp_points), float(mlp_launches)
 
+    # the other arithmetic mode on the same rays, outside the timed region above: 1 warm-up + 2 timed frames,
+    # reported in `other_precision` so that both kernels' numbers come from one run
+    other = None
+    if not args.no_other_precision:
+        alt = "f32" if precision == "f16x2" else "f16x2"
+        ctx.set_precision(alt)
+        step()
+        fence()
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step()
+        fence()
+        dt_alt = time.perf_counter() - t1
+        ctx.profile_enable(False)
+        a_ms, a_launches, a_points = ctx.profile_read(reset=True)
+        ctx.set_precision(precision)
+        ta = torch.tensor([dt_alt], device="cuda", dtype=torch.float64)
+        if use_dist:
+            dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+        dt_alt = float(ta[0])
+        a_tf = a_points / max(a_launches, 1) * FLOP_PER_EVAL / max(a_ms / max(a_launches, 1) * 1e-3, 1e-12) / 1e12
+        a_peak = PEAK_FP32_MFMA_TFLOPS if alt == "f32" else PEAK_FP16_MFMA_TFLOPS / 3
+        other = {"precision": alt, "steps": 2, "ms_per_step": dt_alt / 2 * 1e3,
+                 "value": n_total * evals_per_ray * 2 / dt_alt, "unit": "ray-samples/s",
+                 "roofline": {"achieved": a_tf, "peak": a_peak, "frac": a_tf / a_peak, "unit": "TFLOP/s",
+                              "avg_launch_ms": a_ms / max(a_launches, 1), "note": "rank 0's kernel time"}}
+
     if rank == 0:
         total_evals = n_total * evals_per_ray * args.steps
         value = total_evals / dt
@@ -223,6 +255,8 @@ def main():
                          "avg_launch_ms": avg_launch_s * 1e3, "flop_per_launch": flop_per_launch,
                          "kernel_time_share": mlp_ms_sum * 1e-3 / world / dt},
         }
+        if other is not None:
+            out["other_precision"] = other
         if world == 1 and not args.no_cpu_baseline:
             # same rays, spread over the whole frame so empty, grazing and opaque rays are all present
             idx = np.linspace(0, n_total - 1, 4096).astype(np.int64)
