@@ -80,6 +80,10 @@ void nerf_ctx_destroy(nerf_ctx* ctx);
  * Takes effect for the following calls on this context; weights loaded earlier stay valid. */
 #define NERF_PRECISION_F32 0
 #define NERF_PRECISION_F16X2 1
+/* The same fp16-pair arithmetic on the other shape of the half-precision matrix pipe (v_mfma_f32_16x16x32_f16, two
+ * 16-point column groups per wavefront; csrc/mlp_kernel_h3.hip): same accuracy, same frame rate on MI355X today
+ * (DESIGN.md section 3.1); kept selectable because the clock the chip holds under this load depends on the shape. */
+#define NERF_PRECISION_F16X2_S16 2
 int nerf_set_precision(nerf_ctx* ctx, int precision);
 int nerf_get_precision(nerf_ctx* ctx);
 /* NERF_PRECISION_F16X2 chooses a layer's per-point output scale from an a-priori bound (largest row sum of |W| x

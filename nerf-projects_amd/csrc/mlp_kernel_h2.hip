@@ -132,30 +132,6 @@ __device__ __forceinline__ Frag4 read_frags(const f32x4* fr, int group) {
     return f;
 }
 
-// the six products of one step, small terms first; PART 0 = the first product, PART 1 = the other five.
-// FIRST: the accumulator tile starts from zero (an inline-constant C operand instead of 16 register writes).
-template <int PART, bool FIRST>
-__device__ __forceinline__ void mma_step(f32x16& acc, const Frag4& f, const XT& x) {
-    if constexpr (PART == 0) {
-        if constexpr (FIRST) {
-            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            acc = mma(f.q[1], x.hi[0], zero);
-        } else {
-            acc = mma(f.q[1], x.hi[0], acc);
-        }
-    } else {
-#ifndef NERF_ABLATE_MFMA
-        acc = mma(f.q[0], x.lo[0], acc);
-#endif
-        acc = mma(f.q[0], x.hi[0], acc);
-#ifndef NERF_ABLATE_MFMA
-        acc = mma(f.q[3], x.hi[1], acc);
-        acc = mma(f.q[2], x.lo[1], acc);
-#endif
-        acc = mma(f.q[2], x.hi[1], acc);
-    }
-}
-
 template <int S>
 struct StepTag {
     static constexpr int value = S;
@@ -165,70 +141,128 @@ struct PartTag {
     static constexpr int value = P;
 };
 
-// Consume the current chunk in NSTEP steps of 6 MFMAs; `cur` holds the fragments of step 0 on entry and
-// of the NEXT chunk's step 0 on exit. One wave per SIMD has nobody to hide LDS latency behind, so the order
-// is pinned with scheduling fences: first MFMA of step n (body part 0); the small reads the body wants for the
-// NEXT step (part 2), the four fragment reads of step n+1 into the other half of a double buffer and this step's
-// LDS-DMA pieces; then the other five MFMAs with the body's vector work spread between them (part 1): 160
-// matrix-pipe cycles for the fragment reads to return. Left to itself hipcc sinks the reads below the step's last
-// MFMA to share registers and waits for them.
-template <int S, int NSTEP, int VALU_PER_MFMA, class Body>
-__device__ __forceinline__ void run_steps(PipeH& p, Frag4& cur, const f32x4* fr, const f32x4* fr_next, Body& body) {
-    if constexpr (S < NSTEP) {
-        body(StepTag<S>{}, PartTag<0>{}, cur);
-        __builtin_amdgcn_sched_barrier(0);
-        STAMP(p, (p.c << 8) | (S << 4) | VALU_PER_MFMA);
-        body(StepTag<S>{}, PartTag<2>{}, cur);   // before the fragment reads: lds_pair_wait counts on that
-        Frag4 nxt = (S + 1 < NSTEP) ? read_frags(fr, (S + 1) * 4) : read_frags(fr_next, 0);
-        // The step's LDS-DMA pieces follow the reads. A piece stalls the issuing wave for ~60 cycles wherever it goes
-        // (MI355X_MICROARCH.md); tried and measured on one box: before the first MFMA +0.4 %, ahead of the reads +1.8 %,
-        // after the last MFMA +1.2 %, between MFMAs 3 and 4 next to the conversion work +9 %.
-#ifndef NERF_ABLATE_DMA
-        constexpr int per = 8 / NSTEP;   // pieces per step
-        if constexpr (S < NSTEP / 2) prefetch_pieces<S * per, (S + 1) * per>(p.g_first, p.l_first);
-        else prefetch_pieces<(S - NSTEP / 2) * per, (S - NSTEP / 2 + 1) * per>(p.g_second, p.l_second);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        body(StepTag<S>{}, PartTag<1>{}, cur);
-        if constexpr (VALU_PER_MFMA > 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+// ---- hand-placed step ------------------------------------------------------------------------------------
+// Four ds_read_b128 issued together behind one MFMA hold the wave's issue for ~90 cycles when all four waves of
+// the CU do it at once (profiles/microbench/step_mix.hip: 6 MFMAs + 4 reads together 104 ns, one read per MFMA gap
+// 95 ns, bare 92). Here every LDS read of a step is its own inline-asm statement in its own MFMA gap, and the waits
+// are counted by hand (LDS returns in order). LDS operations of a step, in issue order:
+//     q0' (after MFMA 0)  q1' (after 1)  q2' (after 2)  q3' (after 3)  then NB bias reads (after MFMA 4)
+// so that
+//     MFMA 0 wants q1 of this step: newer are q2, q3 and the NB bias reads        -> lgkmcnt(2 + NB)
+//     the conversion wants the bias reads: newer is q0'                           -> lgkmcnt(1), which also covers q2, q3
+//     without bias reads MFMA 3 wants q3: newer are q0', q1', q2'                  -> lgkmcnt(3)
+// A count that is too small only waits longer; the pattern above is kept across chunk boundaries (a chunk's last step
+// issues no bias read, the next chunk issues its first ones before its step 0), and everything else that reads LDS
+// between chunks waits for lgkmcnt(0).
+template <int OFF>
+__device__ __forceinline__ void frag_issue(f32x4& q, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(q) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+#define NERF_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// MFMA K (0..5) of a step, small terms first
+template <int K, bool FIRST>
+__device__ __forceinline__ void mma_one(f32x16& acc, const Frag4& f, const XT& x) {
+    if constexpr (K == 0) {
+        if constexpr (FIRST) {
+            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            acc = mma(f.q[1], x.hi[0], zero);
+        } else {
+            acc = mma(f.q[1], x.hi[0], acc);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
-        if constexpr (S == NSTEP / 2 - 1) {
-#if defined(NERF_ABLATE_VMWAIT)
-            asm volatile("s_barrier" ::: "memory");
-#elif defined(NERF_ABLATE_BARRIER)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#else
-            asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        run_steps<S + 1, NSTEP, VALU_PER_MFMA>(p, cur, fr, fr_next, body);
+    } else if constexpr (K == 1) {
+        acc = mma(f.q[0], x.lo[0], acc);
+    } else if constexpr (K == 2) {
+        acc = mma(f.q[0], x.hi[0], acc);
+    } else if constexpr (K == 3) {
+        acc = mma(f.q[3], x.hi[1], acc);
+    } else if constexpr (K == 4) {
+        acc = mma(f.q[2], x.lo[1], acc);
+    } else {
+        acc = mma(f.q[2], x.hi[1], acc);
     }
 }
 
-template <int NSTEP, int VALU_PER_MFMA, class Body>
+// body(step, part, frags): part 0..5 = that MFMA; part 11, 12, 13 = the vector work placed behind MFMA 1, 2, 3;
+// part 14 = the bias requests for the next step, behind MFMA 4
+template <int S, int NSTEP, int NB, class Body>
+__device__ __forceinline__ void run_steps(PipeH& p, Frag4& cur, unsigned fr, unsigned fr_next, Body& body) {
+    if constexpr (S < NSTEP) {
+        constexpr bool last = S + 1 == NSTEP;
+        constexpr int G = last ? 0 : (S + 1) * 4;
+        const unsigned ad = last ? fr_next : fr;
+        Frag4 nxt;
+        NERF_FENCE();
+        lgkm_wait<2 + NB>();
+        NERF_FENCE();
+        body(StepTag<S>{}, PartTag<0>{}, cur);
+        NERF_FENCE();
+        STAMP(p, (p.c << 8) | (S << 4) | NB);
+        frag_issue<(G + 0) * 1024>(nxt.q[0], ad);
+#ifndef NERF_ABLATE_DMA
+        {
+            constexpr int per = 8 / NSTEP;
+            if constexpr (S < NSTEP / 2) prefetch_pieces<S * per, (S + 1) * per>(p.g_first, p.l_first);
+            else prefetch_pieces<(S - NSTEP / 2) * per, (S - NSTEP / 2 + 1) * per>(p.g_second, p.l_second);
+        }
+#endif
+        NERF_FENCE();
+        body(StepTag<S>{}, PartTag<1>{}, cur);
+        NERF_FENCE();
+        if constexpr (NB > 0) {
+            lgkm_wait<1>();
+            NERF_FENCE();
+        }
+        body(StepTag<S>{}, PartTag<11>{}, cur);
+        frag_issue<(G + 1) * 1024>(nxt.q[1], ad);
+        NERF_FENCE();
+        body(StepTag<S>{}, PartTag<2>{}, cur);
+        NERF_FENCE();
+        body(StepTag<S>{}, PartTag<12>{}, cur);
+        frag_issue<(G + 2) * 1024>(nxt.q[2], ad);
+        NERF_FENCE();
+        if constexpr (NB == 0) {
+            lgkm_wait<3>();
+            NERF_FENCE();
+        }
+        body(StepTag<S>{}, PartTag<3>{}, cur);
+        NERF_FENCE();
+        body(StepTag<S>{}, PartTag<13>{}, cur);
+        frag_issue<(G + 3) * 1024>(nxt.q[3], ad);
+        NERF_FENCE();
+        body(StepTag<S>{}, PartTag<4>{}, cur);
+        NERF_FENCE();
+        body(StepTag<S>{}, PartTag<14>{}, cur);
+        NERF_FENCE();
+        body(StepTag<S>{}, PartTag<5>{}, cur);
+        NERF_FENCE();
+        cur = nxt;
+        if constexpr (S == NSTEP / 2 - 1) {
+            asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            NERF_FENCE();
+        }
+        run_steps<S + 1, NSTEP, NB>(p, cur, fr, fr_next, body);
+    }
+}
+
+template <int NSTEP, int NB, class Body>
 __device__ __forceinline__ void consume_chunk(PipeH& p, Frag4& cur, Body body) {
-    const f32x4* fr = ring_frags(p, p.b);
-    const f32x4* fr_next = ring_frags(p, ringh_next(p.b, 1));
+    const unsigned fr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)(p.lds + p.b * kChunkBytes) + p.lane * 16;
+    const unsigned fr_next = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)(p.lds + ringh_next(p.b, 1) * kChunkBytes) + p.lane * 16;
     const int c2 = p.c + 2 < p.n ? p.c + 2 : p.c + 2 - p.n;   // wraps into the next tile's stream
     const int c3 = p.c + 3 < p.n ? p.c + 3 : p.c + 3 - p.n;
     p.g_first = piece_src(p, c2) + 4096;
     p.l_first = piece_dst(p, ringh_next(p.b, 2)) + 4096;
     p.g_second = piece_src(p, c3);
     p.l_second = piece_dst(p, ringh_next(p.b, 3));
-    run_steps<0, NSTEP, VALU_PER_MFMA>(p, cur, fr, fr_next, body);
+    run_steps<0, NSTEP, NB>(p, cur, fr, fr_next, body);
     ++p.c;
     p.b = ringh_next(p.b, 1);
 }
-
 // ---- per-point scaling and the fp16 split --------------------------------------------------------
 // exponent t such that max * 2^t lies in [2^9, 2^10): headroom of 64 below the fp16 maximum
 __device__ __forceinline__ int pick_exponent(float m) {
@@ -341,12 +375,6 @@ __device__ __forceinline__ f32x2 lds_pair_issue(unsigned addr) {
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(r) : "v"(addr), "n"(OFF) : "memory");
     return r;
 }
-// valid when at least NEWER LDS reads were issued after the pair's (run_steps issues four fragment reads per step)
-template <int NEWER>
-__device__ __forceinline__ void lds_pair_wait(f32x2& r) {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(NEWER) : "memory");
-}
-
 // ---- the layer whose raw sums wait to become the next layer's operands -------------------------------------
 // A layer's 8 accumulator tiles are not converted when the layer ends but one tile per chunk of the NEXT layer
 // (which accumulates into the other accumulator set), one register pair per MFMA step, in the shadow of the
@@ -397,6 +425,34 @@ __device__ __forceinline__ void convert_tile(XT& dst, const f32x16& src, Pending
     convert_pairs<0>(dst, src, pd, b);
 }
 
+// convert_pair cut into the three slices that ride behind MFMAs 1, 2 and 3 of a step
+struct ConvTmp {
+    float y0, y1, a0, a1;
+};
+template <int P>
+__device__ __forceinline__ void conv_slice0(ConvTmp& t, const f32x16& src, const Pending& pd, const f32x2& b) {
+    t.y0 = fmaxf(fmaf(src[2 * P], pd.c, b[0]), pd.floor);
+    t.y1 = fmaxf(fmaf(src[2 * P + 1], pd.c, b[1]), pd.floor);
+}
+__device__ __forceinline__ void conv_slice1(ConvTmp& t, Pending& pd) {
+    pd.m = fmaxf(fmaxf(pd.m, fabsf(t.y0)), fabsf(t.y1));
+    t.a0 = t.y0 * pd.sc;
+    t.a1 = t.y1 * pd.sc;
+}
+template <int P>
+__device__ __forceinline__ void conv_slice2(XT& dst, const ConvTmp& t) {
+    unsigned hi, lo;
+    // one statement: the half-register writes of v_fma_mixlo / mixhi want an instruction between them, not an s_nop
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "s_nop 0\n\t"
+        "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(hi), "=&v"(lo)
+        : "v"(t.a0), "v"(t.a1));
+    dst.hi[P >> 2][P & 3] = hi;
+    dst.lo[P >> 2][P & 3] = lo;
+}
+
 // chunk kinds (group order: pack_weights.cpp, each unit of four groups re-cut into [k-slice][hi|lo] by
 // convert_stream_h2 below). CONV >= 0: while the chunk runs, step s converts register pair s of pending tile CONV;
 // its two bias entries are requested one step earlier.
@@ -404,66 +460,67 @@ template <int CONV, bool FIRST>
 __device__ __forceinline__ void chunk_ktile8(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x, XT (&hid)[8],
                                              const f32x16 (&pend)[8], Pending& pd) {
     constexpr int C0 = CONV < 0 ? 0 : CONV;
-    f32x2 r;   // requested at the end of the previous step (after that step's conversion): one register pair, not two
+    f32x2 r;
+    ConvTmp t;
     if constexpr (CONV >= 0) r = lds_pair_issue<128 * C0>(pd.bias_addr);
-    consume_chunk<8, (CONV >= 0 ? 3 : 0)>(p, cur, [&](auto tag, auto part, const Frag4& f) {
+    consume_chunk<8, (CONV >= 0 ? 1 : 0)>(p, cur, [&](auto tag, auto part, const Frag4& f) {
         constexpr int s = decltype(tag)::value, pt = decltype(part)::value;
-        if constexpr (pt != 2) {
-            mma_step<pt, FIRST>(acc[s], f, x);
-            if constexpr (pt == 1 && CONV >= 0) {
-                lds_pair_wait<4>(r);   // newer: this step's four fragment reads
-                convert_pair<s>(hid[C0], pend[C0], pd, r);
-                if constexpr (s < 7) r = lds_pair_issue<128 * C0 + 8 * (s + 1)>(pd.bias_addr);
-            }
+        if constexpr (pt < 6) mma_one<pt, FIRST>(acc[s], f, x);
+        else if constexpr (CONV >= 0) {
+            if constexpr (pt == 11) conv_slice0<s>(t, pend[C0], pd, r);
+            else if constexpr (pt == 12) conv_slice1(t, pd);
+            else if constexpr (pt == 13) conv_slice2<s>(hid[C0], t);
+            else if constexpr (pt == 14 && s < 7) r = lds_pair_issue<128 * C0 + 8 * (s + 1)>(pd.bias_addr);
         }
     });
 }
-// one k-tile against 4 output tiles (direction part of the view layer)
 __device__ __forceinline__ void chunk_ktile4(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x) {
     consume_chunk<4, 0>(p, cur, [&](auto tag, auto part, const Frag4& f) {
-        if constexpr (decltype(part)::value != 2) mma_step<decltype(part)::value, false>(acc[decltype(tag)::value], f, x);
+        constexpr int s = decltype(tag)::value, pt = decltype(part)::value;
+        if constexpr (pt < 6) mma_one<pt, false>(acc[s], f, x);
     });
 }
-// two k-tiles against 4 output tiles (feature part of the view layer): steps 0-3 use x0, 4-7 use x1; converts
-// pending tiles CONV and CONV + 1 meanwhile (two register pairs per step)
 template <int CONV, bool FIRST>
 __device__ __forceinline__ void chunk_pair4(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x0, const XT& x1,
                                             XT (&hid)[8], const f32x16 (&pend)[8], Pending& pd) {
     constexpr int C0 = CONV < 0 ? 0 : CONV;
-    f32x2 r0[2], r1[2];
+    f32x2 r0, r1;
+    ConvTmp t0, t1;
     if constexpr (CONV >= 0) {
-        r0[0] = lds_pair_issue<128 * C0>(pd.bias_addr);
-        r1[0] = lds_pair_issue<128 * (C0 + 1)>(pd.bias_addr);
+        r0 = lds_pair_issue<128 * C0>(pd.bias_addr);
+        r1 = lds_pair_issue<128 * (C0 + 1)>(pd.bias_addr);
     }
-    consume_chunk<8, (CONV >= 0 ? 6 : 0)>(p, cur, [&](auto tag, auto part, const Frag4& f) {
+    consume_chunk<8, (CONV >= 0 ? 2 : 0)>(p, cur, [&](auto tag, auto part, const Frag4& f) {
         constexpr int s = decltype(tag)::value, pt = decltype(part)::value;
-        if constexpr (pt == 2) {
-            if constexpr (CONV >= 0 && s < 7) {
-                r0[(s + 1) & 1] = lds_pair_issue<128 * C0 + 8 * (s + 1)>(pd.bias_addr);
-                r1[(s + 1) & 1] = lds_pair_issue<128 * (C0 + 1) + 8 * (s + 1)>(pd.bias_addr);
-            }
-        } else {
-            if constexpr (s < 4) mma_step<pt, FIRST>(acc[s & 3], f, x0);
-            else mma_step<pt, false>(acc[s & 3], f, x1);
-            if constexpr (pt == 1 && CONV >= 0) {
-                lds_pair_wait<6>(r1[s & 1]);
-                convert_pair<s>(hid[C0], pend[C0], pd, r0[s & 1]);
-                convert_pair<s>(hid[C0 + 1], pend[C0 + 1], pd, r1[s & 1]);
+        if constexpr (pt < 6) {
+            if constexpr (s < 4) mma_one<pt, FIRST>(acc[s & 3], f, x0);
+            else mma_one<pt, false>(acc[s & 3], f, x1);
+        } else if constexpr (CONV >= 0) {
+            if constexpr (pt == 11) {
+                conv_slice0<s>(t0, pend[C0], pd, r0);
+                conv_slice0<s>(t1, pend[C0 + 1], pd, r1);
+            } else if constexpr (pt == 12) {
+                conv_slice1(t0, pd);
+                conv_slice1(t1, pd);
+            } else if constexpr (pt == 13) {
+                conv_slice2<s>(hid[C0], t0);
+                conv_slice2<s>(hid[C0 + 1], t1);
+            } else if constexpr (pt == 14 && s < 7) {
+                r0 = lds_pair_issue<128 * C0 + 8 * (s + 1)>(pd.bias_addr);
+                r1 = lds_pair_issue<128 * (C0 + 1) + 8 * (s + 1)>(pd.bias_addr);
             }
         }
     });
 }
-// 8 k-tiles against ONE output tile: step s = k-tile s
 __device__ __forceinline__ void chunk_row8(PipeH& p, Frag4& cur, f32x16& acc, const XT (&x)[8]) {
     consume_chunk<8, 0>(p, cur, [&](auto tag, auto part, const Frag4& f) {
         constexpr int s = decltype(tag)::value, pt = decltype(part)::value;
-        if constexpr (pt != 2) {
-            if constexpr (s == 0) mma_step<pt, true>(acc, f, x[0]);
-            else mma_step<pt, false>(acc, f, x[s]);
+        if constexpr (pt < 6) {
+            if constexpr (s == 0) mma_one<pt, true>(acc, f, x[0]);
+            else mma_one<pt, false>(acc, f, x[s]);
         }
     });
 }
-
 // y = relu(acc * c + bias) for the view layer's 4 tiles (the last layer: nothing to overlap with)
 __device__ __forceinline__ void finish_views(f32x16 (&y)[4], const f32x16 (&acc)[8], unsigned bias_addr, float c) {
     Tile16 nxt = lds_tile_issue(bias_addr);

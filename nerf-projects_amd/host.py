@@ -48,7 +48,7 @@ class Context:
         if default:
             self.set_precision(default)
 
-    PRECISIONS = {"f32": 0, "f16x2": 1}
+    PRECISIONS = {"f32": 0, "f16x2": 1, "f16x2_s16": 2}
 
     def set_precision(self, name):
         """Arithmetic of the fused MLP kernel: "f32" (fp32 MFMA) or "f16x2" (exact fp16-pair split, 3 MFMAs per term)."""

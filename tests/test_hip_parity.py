@@ -14,7 +14,7 @@ from nerf_projects_amd import synthetic
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["f16x2", "f32"])
+@pytest.fixture(scope="module", params=["f16x2", "f32", "f16x2_s16"])
 def N(request):
     """The package with the fused MLP kernel in one of its two arithmetic modes: every parity test runs against the
     default fp16-pair kernel and against the fp32-MFMA kernel (include/nerf_mi355x.h, nerf_set_precision)."""
@@ -69,12 +69,13 @@ def test_precision_switch_abi(N):
         net = make_net(N, synthetic.synthetic_state_dict(7))
         x = gpu(load_golden("mlp_forward")["embedded"])
         out = {}
-        for p in ("f16x2", "f32", "f16x2"):
+        for p in ("f16x2", "f32", "f16x2_s16", "f16x2"):
             ctx.set_precision(p)
             assert ctx.get_precision() == p and lib.nerf_get_precision(ctx.handle) == ctx.PRECISIONS[p]
             out.setdefault(p, []).append(cpu(net(x)))
         assert np.array_equal(out["f16x2"][0], out["f16x2"][1])          # deterministic, unaffected by the detour
         assert np.abs(out["f16x2"][0] - out["f32"][0]).max() <= 1e-5 * np.abs(out["f32"][0]).max()
+        assert np.abs(out["f16x2_s16"][0] - out["f32"][0]).max() <= 1e-5 * np.abs(out["f32"][0]).max()
     finally:
         ctx.set_precision(mine)
 
@@ -183,14 +184,15 @@ def test_mlp_precisions_vs_fp64(N, case):
     mine = ctx.get_precision()
     err = {}
     try:
-        for p in ("f32", "f16x2"):
+        for p in ("f32", "f16x2", "f16x2_s16"):
             ctx.set_precision(p)
             e = np.abs(cpu(net(x)).astype(np.float64) - want) / scale
             err[p] = (np.sqrt((e ** 2).mean()), e.max())
     finally:
         ctx.set_precision(mine)
-    assert err["f16x2"][0] <= 1.25 * err["f32"][0] + 1e-8, err
-    assert err["f16x2"][1] <= 2.0 * err["f32"][1] + 1e-7, err
+    for p in ("f16x2", "f16x2_s16"):
+        assert err[p][0] <= 1.25 * err["f32"][0] + 1e-8, (p, err)
+        assert err[p][1] <= 2.0 * err["f32"][1] + 1e-7, (p, err)
     assert err[mine][0] <= 2e-6 and err[mine][1] <= 2e-5, err
 
 
