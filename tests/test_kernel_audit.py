@@ -1,0 +1,40 @@
+"""Static audit of the fused MLP kernels' hand-counted LDS waits (tools/audit_lds_waits.py).
+
+The fp16-pair kernels read LDS from inline asm and wait with hand-counted `s_waitcnt lgkmcnt(N)`; hipcc neither counts
+those reads nor knows their destinations are in flight. The audit walks the generated assembly of every input mode of
+both kernels and fails if any instruction touches a register before the wait that retires its read - which covers both
+a wait whose count is too large and a compiler move / spill of a destination register. CPU only: hipcc cross-compiles
+the device code to assembly (no GPU, the in-tree library is not touched)."""
+import importlib.util
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "nerf-projects_amd")
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("src", ["mlp_kernel_h2.hip", "mlp_kernel_h3.hip"])
+def test_no_register_touched_before_its_lds_wait(src, tmp_path):
+    build = _load(os.path.join(PKG, "build.py"), "nerf_build_for_audit")
+    audit = _load(os.path.join(ROOT, "tools", "audit_lds_waits.py"), "audit_lds_waits")
+    out = tmp_path / (src + ".s")
+    cmd = [build.hipcc()] + build.FLAGS + build.EXTRA.get(src, build.VGPR_FORM) + \
+        ["-I", os.path.join(ROOT, "include"), "-I", build.CSRC, "--cuda-device-only", "-S",
+         os.path.join(build.CSRC, src), "-o", str(out)]
+    subprocess.run(cmd, check=True, cwd=tmp_path)
+    seen = 0
+    for mode in (0, 1, 2):
+        findings, n_ops, n_waits = audit.audit(str(out), f"kernelILi{mode}")
+        assert n_ops > 1000 and n_waits > 400, (mode, n_ops, n_waits)   # the kernel was found and parsed
+        assert not findings, (mode, findings[:5])
+        seen += 1
+    assert seen == 3

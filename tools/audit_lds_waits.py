@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Audit of the hand-counted LDS waits in the fused MLP kernels' generated code.
+
+The fp16-pair kernels (csrc/mlp_kernel_h2.hip, mlp_kernel_h3.hip) issue their LDS reads from inline asm and wait for
+them with hand-counted `s_waitcnt lgkmcnt(N)` statements, which pins the ORDER of the statements but not what hipcc
+does with the destination registers in between (cdna_hip_programming.md, "What hipcc does not do", item 1). This script
+walks the assembly of a kernel (hipcc -save-temps output) in program order, keeps the queue of LDS operations in
+flight (LDS returns in order: `lgkmcnt(N)` retires all but the newest N) and reports every instruction that reads or
+writes a register whose ds_read has not been retired yet. Loop bodies are straight-line code; at a label or branch the
+queue is kept (a back edge re-enters with the same pattern).
+
+    python tools/audit_lds_waits.py nerf-projects_amd/build/mlp_kernel_h2-hip-amdgcn-amd-amdhsa-gfx950.s [kernel-substring]
+"""
+import re
+import sys
+
+REG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
+
+
+def regs(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1):
+            out.update((m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1))
+        else:
+            out.add((m.group(4), int(m.group(5))))
+    return out
+
+
+def audit(path, want="kernelILi2"):
+    lines = open(path).read().split("\n")
+    findings, n_reads, n_waits = [], 0, 0
+    name, queue = None, []          # queue: list of (line_no, dest_regs) of LDS ops in flight, oldest first
+    for no, raw in enumerate(lines, 1):
+        line = raw.split(";")[0].strip()
+        if not line:
+            continue
+        if line.endswith(":") and not line.startswith("."):
+            name, queue = (line[:-1] if want in line else None), []
+            continue
+        if name is None or line.startswith("."):
+            continue
+        if line.startswith("s_endpgm"):
+            name = None
+            continue
+        op, _, rest = line.partition(" ")
+        m = re.match(r"s_waitcnt\b(.*)", line)
+        if m:
+            c = re.search(r"lgkmcnt\((\d+)\)", line)
+            if c:
+                n_waits += 1
+                keep = int(c.group(1))
+                queue = queue[len(queue) - keep:] if keep else []
+            continue
+        touched = regs(rest)
+        pending = set().union(*[d for _, d in queue]) if queue else set()
+        if op.startswith("ds_") or op.startswith("s_load") or op.startswith("s_buffer_load"):
+            # the address operand of a new LDS op may not be a pending destination either
+            dest = regs(rest.split(",")[0]) if op.startswith("ds_read") or op.startswith("ds_bpermute") or op.startswith("ds_swizzle") else set()
+            srcs = touched - dest
+            # a second LDS read into a register still in flight is harmless (in-order return: the later data lands
+            # last; hipcc does this for destinations nobody consumes, e.g. the T1 fragments of a one-row layer)
+            if srcs & pending:
+                findings.append((no, raw.strip(), sorted(srcs & pending)[:4]))
+            queue.append((no, dest))
+            n_reads += 1
+            continue
+        if touched & pending:
+            findings.append((no, raw.strip(), sorted(touched & pending)[:4]))
+    return findings, n_reads, n_waits
+
+
+if __name__ == "__main__":
+    f, r, w = audit(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "kernelILi2")
+    print(f"{sys.argv[1]}: {r} LDS operations, {w} lgkmcnt waits, {len(f)} accesses to registers still in flight")
+    for no, text, which in f[:40]:
+        print(f"  line {no}: {text}    <- {which}")
+    sys.exit(1 if f else 0)
