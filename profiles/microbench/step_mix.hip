@@ -316,6 +316,16 @@ void step_shape32_kernel(const char* stream, float* out, int steps, const f32x4*
             asm volatile("s_waitcnt vmcnt(3)\n\tds_write_b128 %1, %0" : "+a"(stage[j]) : "v"(la) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(stage[j]) : "v"(g + j * 1024), "0"(stage[j]) : "memory");
         }
+        if (DMA == 3) {   // scalar base + 32-bit lane offset instead of a 64-bit address per lane
+            const unsigned voff = wave * 8192 + lane * 16 + j * 1024;
+            const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(l + j * 1024));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(stream), "s"(la) : "memory");
+        }
+        if (DMA == 4) {   // buffer form: descriptor + 32-bit lane offset
+            const unsigned voff = wave * 8192 + lane * 16 + j * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)stream, 0, 1 << 20, 0x00020000),
+                                                     LDS_PTR(l + j * 1024), 16, voff, 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         MMA32B(q0, bl0);
         MMA32B(q0, bh0);
@@ -342,7 +352,7 @@ void step_shape32_kernel(const char* stream, float* out, int steps, const f32x4*
         if (READS) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3)::"memory");
         q0 = n0; q1 = n1; q2 = n2; q3 = n3;
         if ((s & 7) == 3) {
-            if (DMA == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (DMA == 1 || DMA >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
         }
       }
@@ -430,6 +440,8 @@ int main() {
             run_shape("16x16x32 x12, reads + LDS-DMA + VALU", step_shape16_kernel<true, 1, true>, stream, out, rnd);
             run_shape("32x32x16 x6, reads + register-staged piece + VALU", step_shape32_kernel<true, 2, true>, stream, out, rnd);
             run_shape("16x16x32 x12, reads + register-staged piece + VALU", step_shape16_kernel<true, 2, true>, stream, out, rnd);
+            run_shape("32x32x16 x6, reads + LDS-DMA (scalar base + lane offset) + VALU", step_shape32_kernel<true, 3, true>, stream, out, rnd);
+            run_shape("32x32x16 x6, reads + LDS-DMA (buffer_load ... lds) + VALU", step_shape32_kernel<true, 4, true>, stream, out, rnd);
             run_shape("32x32x16 x6, reads + VALU (no weight traffic)", step_shape32_kernel<true, 0, true>, stream, out, rnd);
             run_shape("16x16x32 x12, reads + VALU (no weight traffic)", step_shape16_kernel<true, 0, true>, stream, out, rnd);
         }

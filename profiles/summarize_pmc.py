@@ -15,6 +15,7 @@ import sys
 import pandas as pd
 
 KERNEL = "nerf_mlp_h2_kernel"   # pass --kernel nerf_mlp_kernel for the fp32 kernel
+SUFFIX = ""                     # --suffix _s16: read pmc_sq_s16/, pmc_l2_s16/ ... (passes of another arithmetic mode)
 
 
 def load(root, name):
@@ -28,21 +29,23 @@ def load(root, name):
 def main(tag, root):
     out = {}
     per = {}
-    for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_l2"):
-        df = load(root, name)
+    have = [n for n in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_l2") if glob.glob(f"{root}/{n}{SUFFIX}/*/*_counter_collection.csv")]
+    for name in have:
+        df = load(root, name + SUFFIX)
         for c, v in df.groupby("Counter_Name").Counter_Value.mean().items():
             per[c] = float(v)
         out[name + "_launches"] = int(df.Dispatch_Id.nunique())
         out[name + "_avg_launch_ms"] = float(df.drop_duplicates("Dispatch_Id").dur_ns.mean() / 1e6)
     out["counters_per_launch_mean"] = per
-    fetch, write = per["FETCH_SIZE"] * 1024, per["WRITE_SIZE"] * 1024
-    out["hbm_bytes_per_launch_uncorrected"] = fetch + write
-    out["hbm_bytes_per_launch_fetch_x2"] = 2 * fetch + write
+    if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
+        fetch, write = per["FETCH_SIZE"] * 1024, per["WRITE_SIZE"] * 1024
+        out["hbm_bytes_per_launch_uncorrected"] = fetch + write
+        out["hbm_bytes_per_launch_fetch_x2"] = 2 * fetch + write
     out["l2_hit_rate"] = per["TCC_HIT_sum"] / (per["TCC_HIT_sum"] + per["TCC_MISS_sum"])
-    l2 = load(root, "pmc_l2")
+    l2 = load(root, "pmc_l2" + SUFFIX)
     g = l2[l2.Counter_Name == "GRBM_GUI_ACTIVE"]
     out["effective_clock_ghz"] = float((g.Counter_Value / 8 / g.dur_ns).mean())
-    sq = load(root, "pmc_sq")
+    sq = load(root, "pmc_sq" + SUFFIX)
     dur = sq.drop_duplicates("Dispatch_Id").dur_ns.mean()
     out["mfma_busy_frac_of_2.4GHz_x_1024_simd"] = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (dur * 2.4 * 1024)
     out["wait_any_frac_of_wave_cycles"] = per["SQ_WAIT_ANY"] / per["SQ_WAVE_CYCLES"]
@@ -67,5 +70,9 @@ if __name__ == "__main__":
     if "--kernel" in sys.argv:
         i = sys.argv.index("--kernel")
         KERNEL = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
+    if "--suffix" in sys.argv:
+        i = sys.argv.index("--suffix")
+        SUFFIX = sys.argv[i + 1]
         del sys.argv[i:i + 2]
     main(sys.argv[1], sys.argv[2])
