@@ -212,6 +212,7 @@ void step_shape16_kernel(const char* stream, float* out, int steps, const f32x4*
     float v0 = lane * 1e-3f, v1 = 0.5f, m = 0.f;
     unsigned hi = 0, lo = 0;
     f32x4 stage[4] = {q0, q0, q0, q0};
+    const bool odd_wave = __builtin_amdgcn_readfirstlane(wave & 1) != 0;
     const f32x4* fr = (const f32x4*)lds + lane;
     const char* g = stream + wave * 8192 + lane * 16;
     char* l = lds + 32768 + wave * 8192;
@@ -229,7 +230,7 @@ void step_shape16_kernel(const char* stream, float* out, int steps, const f32x4*
             asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
                          "ds_read_b128 %3, %4 offset:3072" : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3) : "v"(ad) : "memory");
         }
-        if (DMA == 1) __builtin_amdgcn_global_load_lds(GLB_PTR(g + (s & 3) * 1024), LDS_PTR(l + (s & 3) * 1024), 16, 0, 0);
+        if (DMA == 1 || (DMA == 5 && !odd_wave)) __builtin_amdgcn_global_load_lds(GLB_PTR(g + (s & 3) * 1024), LDS_PTR(l + (s & 3) * 1024), 16, 0, 0);
         if (DMA == 2) {
             const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(l + j * 1024) + lane * 16;
             asm volatile("s_waitcnt vmcnt(3)\n\tds_write_b128 %1, %0" : "+a"(stage[j]) : "v"(la) : "memory");
@@ -242,6 +243,7 @@ void step_shape16_kernel(const char* stream, float* out, int steps, const f32x4*
         MMA16B(q0, bh0, a0);
         MMA16B(q0, bh1, a1);
         MMA16B(q3, bh0, c0);
+        if (DMA == 5 && odd_wave) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_global_load_lds(GLB_PTR(g + (s & 3) * 1024), LDS_PTR(l + (s & 3) * 1024), 16, 0, 0); __builtin_amdgcn_sched_barrier(0); }
         MMA16B(q3, bh1, c1);
         MMA16B(q2, bl0, c0);
         MMA16B(q2, bl1, c1);
@@ -267,7 +269,7 @@ void step_shape16_kernel(const char* stream, float* out, int steps, const f32x4*
         if (READS) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3)::"memory");
         q0 = n0; q1 = n1; q2 = n2; q3 = n3;
         if ((s & 7) == 3) {
-            if (DMA == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (DMA == 1 || DMA == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
         }
       }
@@ -293,6 +295,7 @@ void step_shape32_kernel(const char* stream, float* out, int steps, const f32x4*
     float v0 = lane * 1e-3f, v1 = 0.5f, m = 0.f;
     unsigned hi = 0, lo = 0;
     f32x4 stage[4] = {q0, q0, q0, q0};
+    const bool odd_wave = __builtin_amdgcn_readfirstlane(wave & 1) != 0;
     const f32x4* fr = (const f32x4*)lds + lane;
     const char* g = stream + wave * 8192 + lane * 16;
     char* l = lds + 32768 + wave * 8192;
@@ -310,7 +313,7 @@ void step_shape32_kernel(const char* stream, float* out, int steps, const f32x4*
             asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
                          "ds_read_b128 %3, %4 offset:3072" : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3) : "v"(ad) : "memory");
         }
-        if (DMA == 1) __builtin_amdgcn_global_load_lds(GLB_PTR(g + (s & 3) * 1024), LDS_PTR(l + (s & 3) * 1024), 16, 0, 0);
+        if (DMA == 1 || (DMA == 5 && !odd_wave)) __builtin_amdgcn_global_load_lds(GLB_PTR(g + (s & 3) * 1024), LDS_PTR(l + (s & 3) * 1024), 16, 0, 0);
         if (DMA == 2) {
             const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(l + j * 1024) + lane * 16;
             asm volatile("s_waitcnt vmcnt(3)\n\tds_write_b128 %1, %0" : "+a"(stage[j]) : "v"(la) : "memory");
@@ -330,6 +333,7 @@ void step_shape32_kernel(const char* stream, float* out, int steps, const f32x4*
         MMA32B(q0, bl0);
         MMA32B(q0, bh0);
         MMA32B(q3, bh1);
+        if (DMA == 5 && odd_wave) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_global_load_lds(GLB_PTR(g + (s & 3) * 1024), LDS_PTR(l + (s & 3) * 1024), 16, 0, 0); __builtin_amdgcn_sched_barrier(0); }
         MMA32B(q2, bl1);
         MMA32B(q2, bh1);
         if (VALU) {
@@ -440,6 +444,8 @@ int main() {
             run_shape("16x16x32 x12, reads + LDS-DMA + VALU", step_shape16_kernel<true, 1, true>, stream, out, rnd);
             run_shape("32x32x16 x6, reads + register-staged piece + VALU", step_shape32_kernel<true, 2, true>, stream, out, rnd);
             run_shape("16x16x32 x12, reads + register-staged piece + VALU", step_shape16_kernel<true, 2, true>, stream, out, rnd);
+            run_shape("32x32x16 x6, reads + LDS-DMA staggered (odd waves 3 MFMAs later) + VALU", step_shape32_kernel<true, 5, true>, stream, out, rnd);
+            run_shape("16x16x32 x12, reads + LDS-DMA staggered (odd waves 6 MFMAs later) + VALU", step_shape16_kernel<true, 5, true>, stream, out, rnd);
             run_shape("32x32x16 x6, reads + LDS-DMA (scalar base + lane offset) + VALU", step_shape32_kernel<true, 3, true>, stream, out, rnd);
             run_shape("32x32x16 x6, reads + LDS-DMA (buffer_load ... lds) + VALU", step_shape32_kernel<true, 4, true>, stream, out, rnd);
             run_shape("32x32x16 x6, reads + VALU (no weight traffic)", step_shape32_kernel<true, 0, true>, stream, out, rnd);
