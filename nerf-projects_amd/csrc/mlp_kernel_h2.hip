@@ -23,146 +23,13 @@
 //     tile, rgb_linear an fp32 dot product on the last layer's values.
 //
 // Cost per layer and wave: 384 MFMAs of 32 cycles against 1024 of 64.
-#include "mlp_inputs.h"
+#include "mlp_pair_common.h"
 
 namespace nerf {
-
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// one 32-feature activation tile as MFMA B operands: k-slice s covers accumulator registers 8s..8s+7
-struct XT {
-    u32x4 hi[2], lo[2];
-};
 
 __device__ __forceinline__ f32x16 mma(const f32x4& a, const u32x4& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
 }
-
-#ifdef NERF_STAMPS
-// diagnostic build: wave 0 of workgroup 0 records (tag, s_memtime) through its first tile. A sample is taken at the
-// start of a step and stored at the start of the NEXT one, after the lgkmcnt(0) the step's first MFMA needs anyway, so
-// that reading the counter (an SMEM return) adds no wait of its own.
-struct Stamper {
-    unsigned long long* buf;
-    unsigned long long t_prev;
-    int tag_prev;
-    int n;
-    bool on;
-};
-__device__ __forceinline__ void stamp(Stamper& st, int tag) {
-    if (st.on) {
-        if (st.n < 4090 && (threadIdx.x & 63) == 0) {
-            st.buf[2 * st.n] = (unsigned long long)st.tag_prev;
-            st.buf[2 * st.n + 1] = st.t_prev;
-        }
-        ++st.n;
-        st.t_prev = __builtin_amdgcn_s_memtime();
-        st.tag_prev = tag;
-    }
-}
-#define STAMP(p, tag) stamp((p).st, (tag))
-#else
-#define STAMP(p, tag) do {} while (0)
-#endif
-
-// ---- weight-stream pipeline ------------------------------------------------------------
-// Four 32 KiB LDS buffers form a ring: while chunk c is consumed (48 MFMAs, ~1500 cycles), chunk c+1 is resident,
-// chunk c+2 half issued and chunk c+3 about to be. A chunk travels as 8 LDS-DMA pieces per wave (1 KiB each), and
-// the pieces are spread over the steps instead of issued in a burst (a burst of 32 KiB of LDS writes stalls the
-// fragment reads of all four waves): the first-half steps of chunk c issue pieces 4..7 of chunk c+2, the
-// second-half steps pieces 0..3 of chunk c+3. One barrier per chunk, mid-chunk:
-//   vmcnt(8)  -> this wave's share of chunk c+1 has landed (only chunk c+2's 8 pieces may be pending)
-//   s_barrier -> every wave's share has, and every wave has finished chunk c-1, whose buffer chunk c+3 takes.
-constexpr int kRingH = 4;
-
-struct PipeH {
-    const char* stream;
-    char* lds;
-    int c, b, n, wave, lane;
-    // LDS-DMA source / destination of the chunk being consumed (set once per chunk, consume_chunk): its
-    // first-half steps move pieces 4..7 of chunk c+2, its second-half steps pieces 0..3 of chunk c+3
-    const char* g_first;
-    const char* g_second;
-    char* l_first;
-    char* l_second;
-#ifdef NERF_STAMPS
-    Stamper st;
-#endif
-};
-
-__device__ __forceinline__ int ringh_next(int b, int k) {
-    b += k;
-    return b >= kRingH ? b - kRingH : b;
-}
-
-__device__ __forceinline__ const char* piece_src(const PipeH& p, int chunk) {
-    return p.stream + (size_t)chunk * kChunkBytes + p.wave * 8192 + p.lane * 16;
-}
-__device__ __forceinline__ char* piece_dst(const PipeH& p, int slot) { return p.lds + slot * kChunkBytes + p.wave * 8192; }
-
-// piece J (0..3) of a half chunk: the instruction's immediate offset moves the global and the LDS address together,
-// so the four pieces of a half share one address register pair and one M0 value
-template <int J>
-__device__ __forceinline__ void prefetch_piece(const char* g, char* l) {
-    __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(l), 16, J * 1024, 0);
-}
-template <int LO, int HI>
-__device__ __forceinline__ void prefetch_pieces(const char* g, char* l) {
-    if constexpr (LO < HI) {
-        prefetch_piece<LO>(g, l);
-        prefetch_pieces<LO + 1, HI>(g, l);
-    }
-}
-
-__device__ __forceinline__ const f32x4* ring_frags(const PipeH& p, int slot) {
-    return (const f32x4*)(p.lds + slot * kChunkBytes) + p.lane;
-}
-
-// A-fragments of one step (one output tile x one k-tile): [k-slice 0 hi, k-slice 0 lo, k-slice 1 hi, k-slice 1 lo]
-struct Frag4 {
-    f32x4 q[4];
-};
-__device__ __forceinline__ Frag4 read_frags(const f32x4* fr, int group) {
-    Frag4 f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f.q[i] = fr[(group + i) * 64];
-    return f;
-}
-
-template <int S>
-struct StepTag {
-    static constexpr int value = S;
-};
-template <int P>
-struct PartTag {
-    static constexpr int value = P;
-};
-
-// ---- hand-placed step ------------------------------------------------------------------------------------
-// Four ds_read_b128 issued together behind one MFMA hold the wave's issue for ~90 cycles when all four waves of
-// the CU do it at once (profiles/microbench/step_mix.hip: 6 MFMAs + 4 reads together 104 ns, one read per MFMA gap
-// 95 ns, bare 92). Here every LDS read of a step is its own inline-asm statement in its own MFMA gap, and the waits
-// are counted by hand (LDS returns in order). LDS operations of a step, in issue order:
-//     q0' (after MFMA 0)  q1' (after 1)  q2' (after 2)  q3' (after 3)  then NB bias reads (after MFMA 4)
-// so that
-//     MFMA 0 wants q1 of this step: newer are q2, q3 and the NB bias reads        -> lgkmcnt(2 + NB)
-//     the conversion wants the bias reads: newer is q0'                           -> lgkmcnt(1), which also covers q2, q3
-//     without bias reads MFMA 3 wants q3: newer are q0', q1', q2'                  -> lgkmcnt(3)
-// A count that is too small only waits longer; the pattern above is kept across chunk boundaries (a chunk's last step
-// issues no bias read, the next chunk issues its first ones before its step 0), and everything else that reads LDS
-// between chunks waits for lgkmcnt(0).
-template <int OFF>
-__device__ __forceinline__ void frag_issue(f32x4& q, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(q) : "v"(addr), "n"(OFF) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void lgkm_wait() {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-}
-#define NERF_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // MFMA K (0..5) of a step, small terms first
 template <int K, bool FIRST>
@@ -187,90 +54,6 @@ __device__ __forceinline__ void mma_one(f32x16& acc, const Frag4& f, const XT& x
     }
 }
 
-// body(step, part, frags): part 0..5 = that MFMA; part 11, 12, 13 = the vector work placed behind MFMA 1, 2, 3;
-// part 14 = the bias requests for the next step, behind MFMA 4
-template <int S, int NSTEP, int NB, class Body>
-__device__ __forceinline__ void run_steps(PipeH& p, Frag4& cur, unsigned fr, unsigned fr_next, Body& body) {
-    if constexpr (S < NSTEP) {
-        constexpr bool last = S + 1 == NSTEP;
-        constexpr int G = last ? 0 : (S + 1) * 4;
-        const unsigned ad = last ? fr_next : fr;
-        Frag4 nxt;
-        NERF_FENCE();
-        lgkm_wait<2 + NB>();
-        NERF_FENCE();
-        body(StepTag<S>{}, PartTag<0>{}, cur);
-        NERF_FENCE();
-        STAMP(p, (p.c << 8) | (S << 4) | NB);
-        frag_issue<(G + 0) * 1024>(nxt.q[0], ad);
-#ifndef NERF_ABLATE_DMA
-        {
-            constexpr int per = 8 / NSTEP;
-            if constexpr (S < NSTEP / 2) prefetch_pieces<S * per, (S + 1) * per>(p.g_first, p.l_first);
-            else prefetch_pieces<(S - NSTEP / 2) * per, (S - NSTEP / 2 + 1) * per>(p.g_second, p.l_second);
-        }
-#endif
-        NERF_FENCE();
-        body(StepTag<S>{}, PartTag<1>{}, cur);
-        NERF_FENCE();
-        if constexpr (NB > 0) {
-            lgkm_wait<1>();
-            NERF_FENCE();
-        }
-        body(StepTag<S>{}, PartTag<11>{}, cur);
-        frag_issue<(G + 1) * 1024>(nxt.q[1], ad);
-        NERF_FENCE();
-        body(StepTag<S>{}, PartTag<2>{}, cur);
-        NERF_FENCE();
-        body(StepTag<S>{}, PartTag<12>{}, cur);
-        frag_issue<(G + 2) * 1024>(nxt.q[2], ad);
-        NERF_FENCE();
-        if constexpr (NB == 0) {
-            lgkm_wait<3>();
-            NERF_FENCE();
-        }
-        body(StepTag<S>{}, PartTag<3>{}, cur);
-        NERF_FENCE();
-        body(StepTag<S>{}, PartTag<13>{}, cur);
-        frag_issue<(G + 3) * 1024>(nxt.q[3], ad);
-        NERF_FENCE();
-        body(StepTag<S>{}, PartTag<4>{}, cur);
-        NERF_FENCE();
-        body(StepTag<S>{}, PartTag<14>{}, cur);
-        NERF_FENCE();
-        body(StepTag<S>{}, PartTag<5>{}, cur);
-        NERF_FENCE();
-        cur = nxt;
-        if constexpr (S == NSTEP / 2 - 1) {
-            asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-            NERF_FENCE();
-        }
-        run_steps<S + 1, NSTEP, NB>(p, cur, fr, fr_next, body);
-    }
-}
-
-template <int NSTEP, int NB, class Body>
-__device__ __forceinline__ void consume_chunk(PipeH& p, Frag4& cur, Body body) {
-    const unsigned fr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)(p.lds + p.b * kChunkBytes) + p.lane * 16;
-    const unsigned fr_next = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)(p.lds + ringh_next(p.b, 1) * kChunkBytes) + p.lane * 16;
-    const int c2 = p.c + 2 < p.n ? p.c + 2 : p.c + 2 - p.n;   // wraps into the next tile's stream
-    const int c3 = p.c + 3 < p.n ? p.c + 3 : p.c + 3 - p.n;
-    p.g_first = piece_src(p, c2) + 4096;
-    p.l_first = piece_dst(p, ringh_next(p.b, 2)) + 4096;
-    p.g_second = piece_src(p, c3);
-    p.l_second = piece_dst(p, ringh_next(p.b, 3));
-    run_steps<0, NSTEP, NB>(p, cur, fr, fr_next, body);
-    ++p.c;
-    p.b = ringh_next(p.b, 1);
-}
-// ---- per-point scaling and the fp16 split --------------------------------------------------------
-// exponent t such that max * 2^t lies in [2^9, 2^10): headroom of 64 below the fp16 maximum
-__device__ __forceinline__ int pick_exponent(float m) {
-    const int t = 10 - __builtin_amdgcn_frexp_expf(m);   // frexp_exp(0) = 0
-    return t < -60 ? -60 : (t > 60 ? 60 : t);   // keeps descale * 2^-t finite
-}
-__device__ __forceinline__ float pow2f(int t) { return __builtin_ldexpf(1.0f, t); }
-
 // max with the partner lane of the other half-wave: v_permlane32_swap on two copies yields (lo, lo) and (hi, hi)
 // - a vector instruction, no trip through the LDS crossbar and no lgkmcnt wait
 __device__ __forceinline__ float half_max(float m) {
@@ -278,46 +61,6 @@ __device__ __forceinline__ float half_max(float m) {
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
 }
-// largest value over the wavefront, as a wave-uniform number (lives in an SGPR)
-__device__ __forceinline__ float wave_max(float m) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
-}
-
-__device__ __forceinline__ float tile_absmax(const f32x16& v, float m) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(v[r]));
-    return m;
-}
-
-// v_cvt_pk_f16_f32: both halves rounded to nearest even. hi = rn16(v) leaves |v - hi| <= 2^-12 |v| (exact in fp32),
-// lo = rn16(v - hi) leaves 2^-24 |v|: the pair carries as many bits as the fp32 it came from.
-__device__ __forceinline__ h16x2 round_pair(float a, float b) {
-    const f32x2 v = {a, b};
-    return __builtin_convertvector(v, h16x2);
-}
-
-// registers 2P, 2P+1 of a tile (already scaled) -> packed (hi, lo)
-template <int P>
-__device__ __forceinline__ void split_pair(XT& out, float a, float b) {
-    const h16x2 hi = round_pair(a, b);
-    // fma(hi, -1, v): the exact remainder, rounded once to fp16 (v_fma_mixlo/mixhi_f16 where hipcc sees the pattern)
-    const h16x2 lo = {(_Float16)__builtin_fmaf((float)hi[0], -1.0f, a), (_Float16)__builtin_fmaf((float)hi[1], -1.0f, b)};
-    out.hi[P >> 2][P & 3] = __builtin_bit_cast(unsigned, hi);
-    out.lo[P >> 2][P & 3] = __builtin_bit_cast(unsigned, lo);
-}
-
-template <int P>
-__device__ __forceinline__ void split_pairs(XT& out, const f32x16& v, float sc) {
-    if constexpr (P < 8) {
-        split_pair<P>(out, v[2 * P] * sc, v[2 * P + 1] * sc);
-        split_pairs<P + 1>(out, v, sc);
-    }
-}
-// v * sc -> (hi, lo) for the 16 registers of one tile
-__device__ __forceinline__ void split_tile(XT& out, const f32x16& v, float sc) { split_pairs<0>(out, v, sc); }
-
 // multiply a split tile by 2^d (exact while nothing leaves the fp16 range)
 __device__ __forceinline__ void rescale_tile(XT& x, int d) {
     const _Float16 f = (_Float16)pow2f(d < -30 ? -30 : (d > 15 ? 15 : d));
@@ -357,23 +100,6 @@ __device__ __forceinline__ Tile16 lds_tile_issue(unsigned addr) {
 }
 __device__ __forceinline__ void lds_tile_wait(Tile16& t) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t.q[0]), "+v"(t.q[1]), "+v"(t.q[2]), "+v"(t.q[3])::"memory");
-}
-__device__ __forceinline__ float lds_scalar(const float* p) {
-    float v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds_addr(p)) : "memory");
-    return v;
-}
-__device__ __forceinline__ f32x4 lds_vec4(const float* p) {
-    f32x4 v;
-    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds_addr(p)) : "memory");
-    return v;
-}
-// the two bias entries of one register pair, `OFF` bytes past `addr`; issued one step ahead of their use
-template <int OFF>
-__device__ __forceinline__ f32x2 lds_pair_issue(unsigned addr) {
-    f32x2 r;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(r) : "v"(addr), "n"(OFF) : "memory");
-    return r;
 }
 // ---- the layer whose raw sums wait to become the next layer's operands -------------------------------------
 // A layer's 8 accumulator tiles are not converted when the layer ends but one tile per chunk of the NEXT layer
@@ -426,9 +152,6 @@ __device__ __forceinline__ void convert_tile(XT& dst, const f32x16& src, Pending
 }
 
 // convert_pair cut into the three slices that ride behind MFMAs 1, 2 and 3 of a step
-struct ConvTmp {
-    float y0, y1, a0, a1;
-};
 template <int P>
 __device__ __forceinline__ void conv_slice0(ConvTmp& t, const f32x16& src, const Pending& pd, const f32x2& b) {
     t.y0 = fmaxf(fmaf(src[2 * P], pd.c, b[0]), pd.floor);
@@ -439,20 +162,6 @@ __device__ __forceinline__ void conv_slice1(ConvTmp& t, Pending& pd) {
     t.a0 = t.y0 * pd.sc;
     t.a1 = t.y1 * pd.sc;
 }
-template <int P>
-__device__ __forceinline__ void conv_slice2(XT& dst, const ConvTmp& t) {
-    unsigned hi, lo;
-    // one statement: the half-register writes of v_fma_mixlo / mixhi want an instruction between them, not an s_nop
-    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
-        "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
-        "s_nop 0\n\t"
-        "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-        : "=&v"(hi), "=&v"(lo)
-        : "v"(t.a0), "v"(t.a1));
-    dst.hi[P >> 2][P & 3] = hi;
-    dst.lo[P >> 2][P & 3] = lo;
-}
-
 // chunk kinds (group order: pack_weights.cpp, each unit of four groups re-cut into [k-slice][hi|lo] by
 // convert_stream_h2 below). CONV >= 0: while the chunk runs, step s converts register pair s of pending tile CONV;
 // its two bias entries are requested one step earlier.
@@ -584,7 +293,14 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
         layer_tab[4 * l + 3] = 0.0f;
     }
     __syncthreads();   // chunks 0, 1, the bias block and the layer tables are in LDS
-    Frag4 cur = read_frags(ring_frags(pipe, 0), 0);
+    Frag4 cur;
+    {
+        const unsigned fr0 = lds_byte_addr(ring_lds) + lane * 16;
+        frag_issue<0>(cur.q[0], fr0);
+        frag_issue<1024>(cur.q[1], fr0);
+        frag_issue<2048>(cur.q[2], fr0);
+        frag_issue<3072>(cur.q[3], fr0);
+    }
 
     const unsigned bias0 = lds_addr(bias_lds) + 64 * h;   // this half-wave's entries of bias-block tile 0
     const int n_layers = a.use_viewdirs ? a.D + 1 : a.D;

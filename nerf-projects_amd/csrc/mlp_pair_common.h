@@ -1,0 +1,293 @@
+// Shared machinery of the two fp16-pair MLP kernels (mlp_kernel_h2.hip: v_mfma_f32_32x32x16_f16, mlp_kernel_h3.hip:
+// v_mfma_f32_16x16x32_f16): the LDS-DMA weight ring, the hand-placed step with its counted LDS waits, the power-of-two
+// scaling and the exact (hi, lo) fp16 split, LDS reads outside hipcc's LDS-DMA guard.
+#pragma once
+#include "mlp_inputs.h"
+
+namespace nerf {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// one 32-feature activation tile as MFMA B operands: two u32x4 of packed halves each for hi and lo (32x32x16 kernel:
+// [k-slice], 16x16x32 kernel: [point group])
+struct XT {
+    u32x4 hi[2], lo[2];
+};
+#ifdef NERF_STAMPS
+// diagnostic build: wave 0 of workgroup 0 records (tag, s_memtime) through its first tile. A sample is taken at the
+// start of a step and stored at the start of the NEXT one, so that reading the counter (an SMEM return) adds no wait
+// of its own.
+struct Stamper {
+    unsigned long long* buf;
+    unsigned long long t_prev;
+    int tag_prev;
+    int n;
+    bool on;
+};
+__device__ __forceinline__ void stamp(Stamper& st, int tag) {
+    if (st.on) {
+        if (st.n < 4090 && (threadIdx.x & 63) == 0) {
+            st.buf[2 * st.n] = (unsigned long long)st.tag_prev;
+            st.buf[2 * st.n + 1] = st.t_prev;
+        }
+        ++st.n;
+        st.t_prev = __builtin_amdgcn_s_memtime();
+        st.tag_prev = tag;
+    }
+}
+#define STAMP(p, tag) stamp((p).st, (tag))
+#else
+#define STAMP(p, tag) do {} while (0)
+#endif
+
+// ---- weight-stream pipeline -------------------------------------------------------------
+// Four 32 KiB LDS buffers form a ring: while chunk c is consumed, chunk c+1 is resident, chunk c+2 half issued and
+// chunk c+3 about to be. A chunk travels as 8 LDS-DMA pieces per wave (1 KiB each), one per step: the first-half steps
+// of chunk c issue pieces 4..7 of chunk c+2, the second-half steps pieces 0..3 of chunk c+3. One barrier per chunk,
+// mid-chunk:
+//   vmcnt(8)  -> this wave's share of chunk c+1 has landed (only chunk c+2's 8 pieces may be pending)
+//   s_barrier -> every wave's share has, and every wave has finished chunk c-1, whose buffer chunk c+3 takes.
+constexpr int kRingH = 4;
+
+struct PipeH {
+    const char* stream;
+    char* lds;
+    int c, b, n, wave, lane;
+    const char* g_first;
+    const char* g_second;
+    char* l_first;
+    char* l_second;
+#ifdef NERF_STAMPS
+    Stamper st;
+#endif
+};
+
+__device__ __forceinline__ int ringh_next(int b, int k) {
+    b += k;
+    return b >= kRingH ? b - kRingH : b;
+}
+__device__ __forceinline__ const char* piece_src(const PipeH& p, int chunk) {
+    return p.stream + (size_t)chunk * kChunkBytes + p.wave * 8192 + p.lane * 16;
+}
+__device__ __forceinline__ char* piece_dst(const PipeH& p, int slot) { return p.lds + slot * kChunkBytes + p.wave * 8192; }
+
+template <int J>
+__device__ __forceinline__ void prefetch_piece(const char* g, char* l) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(l), 16, J * 1024, 0);
+}
+template <int LO, int HI>
+__device__ __forceinline__ void prefetch_pieces(const char* g, char* l) {
+    if constexpr (LO < HI) {
+        prefetch_piece<LO>(g, l);
+        prefetch_pieces<LO + 1, HI>(g, l);
+    }
+}
+
+// A-fragments of one step: [T0 hi, T0 lo, T1 hi, T1 lo]
+struct Frag4 {
+    f32x4 q[4];
+};
+
+// ---- hand-placed step ------------------------------------------------------------------------------------------
+// Every LDS read of a step is its own inline-asm statement in its own MFMA gap and the waits are counted by hand (LDS
+// returns in order; hipcc would guard reads it can see with vmcnt(0) while an LDS-DMA is in flight, and four
+// ds_read_b128 issued together stall the wave, profiles/microbench/step_mix.hip). LDS operations of a step, in issue
+// order:   q0' (after MFMA pair 0)  q1' (after 1)  q2' (after 2)  q3' (after 3)  then NB bias reads (after pair 4)
+// so that
+//     pair 0 wants q1 (and pair 1, 2 q0) of this step: newer are q2, q3 and the NB bias reads -> lgkmcnt(2 + NB)
+//     the conversion wants the bias reads: newer is q0'                                       -> lgkmcnt(1), covers q2, q3
+//     without bias reads pair 3 wants q3: newer are q0', q1', q2'                              -> lgkmcnt(3)
+// A count that is too small only waits longer; the pattern is kept across chunk boundaries (a chunk's last step issues
+// no bias read, the next chunk issues its first ones before its step 0), and everything else that reads LDS between
+// chunks waits for lgkmcnt(0).
+template <int OFF>
+__device__ __forceinline__ void frag_issue(f32x4& q, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(q) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+#define NERF_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int S>
+struct StepTag {
+    static constexpr int value = S;
+};
+template <int P>
+struct PartTag {
+    static constexpr int value = P;
+};
+
+// body(step, part, frags): part 0..5 = that MFMA pair; part 11, 12, 13 = the vector work placed behind pairs 1, 2, 3;
+// part 14 = the bias requests for the next step, behind pair 4
+template <int S, int NSTEP, int NB, class Body>
+__device__ __forceinline__ void run_steps(PipeH& p, Frag4& cur, unsigned fr, unsigned fr_next, Body& body) {
+    if constexpr (S < NSTEP) {
+        constexpr bool last = S + 1 == NSTEP;
+        constexpr int G = last ? 0 : (S + 1) * 4;
+        const unsigned ad = last ? fr_next : fr;
+        Frag4 nxt;
+        NERF_FENCE();
+        lgkm_wait<2 + NB>();
+        NERF_FENCE();
+        body(StepTag<S>{}, PartTag<0>{}, cur);
+        NERF_FENCE();
+        STAMP(p, (p.c << 8) | (S << 4) | NB);
+        frag_issue<(G + 0) * 1024>(nxt.q[0], ad);
+#ifndef NERF_ABLATE_DMA
+        {
+            constexpr int per = 8 / NSTEP;
+            if constexpr (S < NSTEP / 2) prefetch_pieces<S * per, (S + 1) * per>(p.g_first, p.l_first);
+            else prefetch_pieces<(S - NSTEP / 2) * per, (S - NSTEP / 2 + 1) * per>(p.g_second, p.l_second);
+        }
+#endif
+        NERF_FENCE();
+        body(StepTag<S>{}, PartTag<1>{}, cur);
+        NERF_FENCE();
+        if constexpr (NB > 0) {
+            lgkm_wait<1>();
+            NERF_FENCE();
+        }
+        body(StepTag<S>{}, PartTag<11>{}, cur);
+        frag_issue<(G + 1) * 1024>(nxt.q[1], ad);
+        NERF_FENCE();
+        body(StepTag<S>{}, PartTag<2>{}, cur);
+        NERF_FENCE();
+        body(StepTag<S>{}, PartTag<12>{}, cur);
+        frag_issue<(G + 2) * 1024>(nxt.q[2], ad);
+        NERF_FENCE();
+        if constexpr (NB == 0) {
+            lgkm_wait<3>();
+            NERF_FENCE();
+        }
+        body(StepTag<S>{}, PartTag<3>{}, cur);
+        NERF_FENCE();
+        body(StepTag<S>{}, PartTag<13>{}, cur);
+        frag_issue<(G + 3) * 1024>(nxt.q[3], ad);
+        NERF_FENCE();
+        body(StepTag<S>{}, PartTag<4>{}, cur);
+        NERF_FENCE();
+        body(StepTag<S>{}, PartTag<14>{}, cur);
+        NERF_FENCE();
+        body(StepTag<S>{}, PartTag<5>{}, cur);
+        NERF_FENCE();
+        cur = nxt;
+        if constexpr (S == NSTEP / 2 - 1) {
+            asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            NERF_FENCE();
+        }
+        run_steps<S + 1, NSTEP, NB>(p, cur, fr, fr_next, body);
+    }
+}
+
+__device__ __forceinline__ unsigned lds_byte_addr(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+template <int NSTEP, int NB, class Body>
+__device__ __forceinline__ void consume_chunk(PipeH& p, Frag4& cur, Body body) {
+    const unsigned fr = lds_byte_addr(p.lds + p.b * kChunkBytes) + p.lane * 16;
+    const unsigned fr_next = lds_byte_addr(p.lds + ringh_next(p.b, 1) * kChunkBytes) + p.lane * 16;
+    const int c2 = p.c + 2 < p.n ? p.c + 2 : p.c + 2 - p.n;   // wraps into the next tile's stream
+    const int c3 = p.c + 3 < p.n ? p.c + 3 : p.c + 3 - p.n;
+    p.g_first = piece_src(p, c2) + 4096;
+    p.l_first = piece_dst(p, ringh_next(p.b, 2)) + 4096;
+    p.g_second = piece_src(p, c3);
+    p.l_second = piece_dst(p, ringh_next(p.b, 3));
+    run_steps<0, NSTEP, NB>(p, cur, fr, fr_next, body);
+    ++p.c;
+    p.b = ringh_next(p.b, 1);
+}
+
+// ---- per-point scaling and the fp16 split --------------------------------------------------
+// exponent t such that max * 2^t lies in [2^9, 2^10): headroom of 64 below the fp16 maximum
+__device__ __forceinline__ int pick_exponent(float m) {
+    const int t = 10 - __builtin_amdgcn_frexp_expf(m);   // frexp_exp(0) = 0
+    return t < -60 ? -60 : (t > 60 ? 60 : t);   // keeps descale * 2^-t finite
+}
+__device__ __forceinline__ float pow2f(int t) { return __builtin_ldexpf(1.0f, t); }
+
+// largest value over the wavefront, as a wave-uniform number (lives in an SGPR)
+__device__ __forceinline__ float wave_max(float m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
+}
+__device__ __forceinline__ float tile_absmax(const f32x16& v, float m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(v[r]));
+    return m;
+}
+
+// v_cvt_pk_f16_f32: both halves rounded to nearest even. hi = rn16(v) leaves |v - hi| <= 2^-12 |v| (exact in fp32),
+// lo = rn16(v - hi) leaves 2^-24 |v|: the pair carries as many bits as the fp32 it came from.
+__device__ __forceinline__ h16x2 round_pair(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_convertvector(v, h16x2);
+}
+// values 2 Pp, 2 Pp + 1 of a tile in [point group][position] order (already scaled) -> packed (hi, lo)
+template <int Pp>
+__device__ __forceinline__ void split_pair(XT& out, float a, float b) {
+    const h16x2 hi = round_pair(a, b);
+    const h16x2 lo = {(_Float16)__builtin_fmaf((float)hi[0], -1.0f, a), (_Float16)__builtin_fmaf((float)hi[1], -1.0f, b)};
+    out.hi[Pp >> 2][Pp & 3] = __builtin_bit_cast(unsigned, hi);
+    out.lo[Pp >> 2][Pp & 3] = __builtin_bit_cast(unsigned, lo);
+}
+template <int Pp>
+__device__ __forceinline__ void split_pairs(XT& out, const f32x16& v, float sc) {
+    if constexpr (Pp < 8) {
+        split_pair<Pp>(out, v[2 * Pp] * sc, v[2 * Pp + 1] * sc);
+        split_pairs<Pp + 1>(out, v, sc);
+    }
+}
+__device__ __forceinline__ void split_tile(XT& out, const f32x16& v, float sc) { split_pairs<0>(out, v, sc); }
+
+// ---- LDS reads outside hipcc's LDS-DMA guard ---------------------------------------------------------------
+// hipcc guards every LDS load it can see with s_waitcnt vmcnt(0) while an LDS-DMA write is in flight (it cannot tell the
+// bias block from the ring), which would drain the weight pipeline at every bias read; these reads are issued from
+// inline asm with their own lgkmcnt wait (LDS returns in order).
+__device__ __forceinline__ float lds_scalar(const float* p) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds_byte_addr(p)) : "memory");
+    return v;
+}
+__device__ __forceinline__ f32x4 lds_vec4(const float* p) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds_byte_addr(p)) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ f32x2 lds_pair_issue(unsigned addr) {
+    f32x2 r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+
+// the last slice of a register pair's conversion: (a0, a1), already scaled -> packed (hi, lo), lo = rn16(a - hi) by one fma
+// with an fp16 source and an fp16 result per half (hipcc does not form these itself). One statement: the two
+// half-register writes want an instruction between them.
+struct ConvTmp {
+    float y0, y1, a0, a1;
+};
+template <int P>
+__device__ __forceinline__ void conv_slice2(XT& dst, const ConvTmp& t) {
+#ifdef NERF_ABLATE_CONV
+    if (P == 0) dst.hi[0][0] = __float_as_uint(t.y0);
+    return;
+#endif
+    unsigned hi, lo;
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "s_nop 0\n\t"
+        "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(hi), "=&v"(lo)
+        : "v"(t.a0), "v"(t.a1));
+    dst.hi[P >> 2][P & 3] = hi;
+    dst.lo[P >> 2][P & 3] = lo;
+}
+
+}  // namespace nerf

@@ -80,13 +80,14 @@ def test_precision_switch_abi(N):
         ctx.set_precision(mine)
 
 
-def test_loose_bound_is_counted_not_silent(N):
+@pytest.mark.parametrize("mode", ["f16x2", "f16x2_s16"])
+def test_loose_bound_is_counted_not_silent(N, mode):
     """nerf_precision_status: zero on ordinary weights; weights whose rows are large but cancel (so that the a-priori
-    bound of the fp16-pair kernel overshoots the real outputs by > 2^12) are reported."""
+    bound of the fp16-pair kernels overshoots the real outputs by > 2^12) are reported."""
     ctx = N.get_context()
     mine = ctx.get_precision()
     try:
-        ctx.set_precision("f16x2")
+        ctx.set_precision(mode)
         x = gpu(load_golden("mlp_forward")["embedded"])
         sd = dict(synthetic.synthetic_state_dict(7))
         net = make_net(N, sd)
