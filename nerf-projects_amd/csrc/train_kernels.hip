@@ -74,44 +74,60 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmRows g) {
     const int n_ct = (g.N + 31) >> 5;           // column tiles in use (<= 8), uniform
     const int n_kt = (g.K + 31) >> 5;
 
-    auto stage = [&](int kt, int buf) {         // loaders only
-        const int k0 = kt * 32;
-        float* as = As + buf * 128 * kLd;
-        float* bs = Bs + buf * 256 * kLd;
+    // The two roles run separate loops with the same barrier count (s_barrier counts arrivals, not program points), so
+    // that each role's registers are allocated on their own. A loader requests k-tile kt + 2 right after it has written
+    // k-tile kt + 1 to LDS: a tile's global loads have a whole consumer period (128 MFMAs) to arrive before they are
+    // needed, instead of sitting between two barriers with the conversion to LDS behind them.
+    if (!consumer) {
         float ra[16], rb[32];
+        auto request = [&](int kt) {
+            const int k0 = kt * 32;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int e = it * 256 + ptid, r = e >> 5, c = e & 31;
-            const int64_t gr = row0 + r;
-            ra[it] = (gr < g.M && k0 + c < g.K) ? g.A[gr * g.lda + k0 + c] : 0.0f;
+            for (int it = 0; it < 16; ++it) {
+                const int e = it * 256 + ptid, r = e >> 5, c = e & 31;
+                const int64_t gr = row0 + r;
+                ra[it] = (gr < g.M && k0 + c < g.K) ? g.A[gr * g.lda + k0 + c] : 0.0f;
+            }
+#pragma unroll
+            for (int it = 0; it < 32; ++it)
+                rb[it] = (k0 + it < g.K && ptid < g.N) ? g.B[(int64_t)(k0 + it) * g.ldb + ptid] : 0.0f;
+        };
+        auto deposit = [&](int buf) {
+            float* as = As + buf * 128 * kLd;
+            float* bs = Bs + buf * 256 * kLd;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int e = it * 256 + ptid;
+                as[(e >> 5) * kLd + (e & 31)] = ra[it];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {           // thread = column n: its 32 k values, 16 bytes at a time
+                f32x4 v = {rb[4 * q], rb[4 * q + 1], rb[4 * q + 2], rb[4 * q + 3]};
+                *(f32x4*)&bs[ptid * kLd + 4 * q] = v;
+            }
+        };
+        request(0);
+        deposit(0);
+        if (n_kt > 1) request(1);
+        __syncthreads();
+        for (int kt = 0; kt < n_kt; ++kt) {
+            if (kt + 1 < n_kt) {
+                deposit((kt + 1) & 1);
+                if (kt + 2 < n_kt) request(kt + 2);
+            }
+            __syncthreads();
         }
-#pragma unroll
-        for (int it = 0; it < 32; ++it)
-            rb[it] = (k0 + it < g.K && ptid < g.N) ? g.B[(int64_t)(k0 + it) * g.ldb + ptid] : 0.0f;
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int e = it * 256 + ptid;
-            as[(e >> 5) * kLd + (e & 31)] = ra[it];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {           // thread = column n: its 32 k values, 16 bytes at a time
-            f32x4 v = {rb[4 * q], rb[4 * q + 1], rb[4 * q + 2], rb[4 * q + 3]};
-            *(f32x4*)&bs[ptid * kLd + 4 * q] = v;
-        }
-    };
+        return;
+    }
 
     f32x16 acc[8];
-    if (consumer) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+    for (int c = 0; c < 8; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
-    } else {
-        stage(0, 0);
-    }
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
     __syncthreads();
     for (int kt = 0; kt < n_kt; ++kt) {
-        if (consumer) {
+        {
             const float* as = As + (kt & 1) * 128 * kLd;
             const float* bs = Bs + (kt & 1) * 256 * kLd;
             const F16 a = frag_at(as, 32 * wave + j, h);
@@ -129,12 +145,9 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmRows g) {
                     cur = nxt;
                 }
             }
-        } else if (kt + 1 < n_kt) {
-            stage(kt + 1, (kt + 1) & 1);
         }
         __syncthreads();
     }
-    if (!consumer) return;
     // D[row][col]: col = lane & 31 (-> n), row = (reg & 3) + 8*(reg >> 2) + 4*h (-> point).
     // The optional reads (old C for accumulate, the ReLU mask) are batched per column tile from clamped
     // addresses under wave-uniform flags, so 16 loads are in flight at a time instead of one.
