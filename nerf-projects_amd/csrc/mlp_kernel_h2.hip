@@ -154,10 +154,17 @@ __device__ __forceinline__ void convert_tile(XT& dst, const f32x16& src, Pending
 // convert_pair cut into the three slices that ride behind MFMAs 1, 2 and 3 of a step
 template <int P>
 __device__ __forceinline__ void conv_slice0(ConvTmp& t, const f32x16& src, const Pending& pd, const f32x2& b) {
+#ifdef NERF_ABLATE_CONV   // timing-only build: one instruction keeps the operands alive
+    t.y0 = src[2 * P] + b[0]; t.y1 = 0.0f;
+    return;
+#endif
     t.y0 = fmaxf(fmaf(src[2 * P], pd.c, b[0]), pd.floor);
     t.y1 = fmaxf(fmaf(src[2 * P + 1], pd.c, b[1]), pd.floor);
 }
 __device__ __forceinline__ void conv_slice1(ConvTmp& t, Pending& pd) {
+#ifdef NERF_ABLATE_CONV
+    return;
+#endif
     pd.m = fmaxf(fmaxf(pd.m, fabsf(t.y0)), fabsf(t.y1));
     t.a0 = t.y0 * pd.sc;
     t.a1 = t.y1 * pd.sc;
