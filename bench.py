@@ -17,9 +17,12 @@ The roofline object prices the fused encode+MLP kernel with HIP events recorded 
 inside the timed region. Default arithmetic ("f16x2"): every fp32 operand is carried exactly as two fp16
 halves and every product costs three v_mfma_f32_32x32x16_f16, so the algorithmic FLOP rate is priced
 against one third of the dense fp16 MFMA peak (2516.6 / 3 = 838.9 TFLOP/s, MI355X_MICROARCH.md);
-`--precision f32` runs the v_mfma_f32_32x32x2_f32 kernel, priced against 157.3 TFLOP/s. After the timed region the
-other mode renders two frames of the same rays and its figures are reported in `other_precision`. The cpu_baseline object times the CPU oracle (numpy port, oracle/nerf_oracle.py) on
-a bounded sample of the same rays; it is reported next to the GPU number, never used by it.
+`--precision f32` runs the v_mfma_f32_32x32x2_f32 kernel, priced against 157.3 TFLOP/s. After the timed region (N=1):
+the other mode renders five timed frames of the same rays (`other_precision`); a short training run reports it/s of
+the reference's loop body (`train`); the `parity` object compares the HIP render of the 4096 fixture rays of this frame
+with the REFERENCE's own fp32 render of them (tests/golden/bench_frame.npz, oracle/parity.py); the `cpu_baseline` object
+times the CPU oracle (oracle/nerf_oracle.py) on a bounded sample of the same rays with the thread count that maximises
+it. These legs are reported next to the GPU number, never used by it.
 """
 import argparse
 import json
@@ -56,7 +59,8 @@ def parse():
     p.add_argument("--precision", default=None, choices=["f16x2", "f32", "f16x2_s16"],
                    help="arithmetic of the fused MLP kernel (default: the library's, f16x2)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
-    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline and parity)")
+    p.add_argument("--no-train", action="store_true", help="skip the short training-throughput leg")
     p.add_argument("--no-other-precision", action="store_true",
                    help="skip the short run in the other arithmetic mode that is reported next to the result")
     p.add_argument("--force-collective", action="store_true",
@@ -65,31 +69,128 @@ def parse():
 
 
 def cpu_baseline(sample_rays, sd_c, sd_f, Sc, Si, white, target_s):
-    """Time the CPU oracle on a bounded sample of the workload's rays (rank 0, N=1 only)."""
+    """Time the CPU oracle on a bounded sample of the workload's rays (rank 0, N=1 only).
+
+    The oracle's GEMMs run through PyTorch's CPU sgemm (oracle.set_gemm_backend("torch"): the BLAS the reference itself
+    uses; numpy's OpenBLAS is ~2.5x slower at equal threads and is timed once for the record). The thread count is the
+    one that maximises the rate on a 512-ray probe, the batch the reference's own netchunk (65536 points)."""
     from oracle import nerf_oracle as O
     net_c = O.NeRF(8, 256, 63, 27, 4, (4,), True, sd_c)
     net_f = O.NeRF(8, 256, 63, 27, 4, (4,), True, sd_f)
     q = O.make_query_fn(O.get_embedder(10)[0], O.get_embedder(4)[0])
     kw = dict(N_samples=Sc, N_importance=Si, network_fine=net_f if Si else None, white_bkgd=white)
-    probe = min(256, len(sample_rays))
-    t0 = time.perf_counter()
-    O.render_rays(sample_rays[:probe], net_c, q, **kw)
-    dt = time.perf_counter() - t0
-    n = int(min(len(sample_rays), max(probe, target_s / max(dt, 1e-6) * probe)))
-    n = max(64, (n // 64) * 64)
-    t0 = time.perf_counter()
-    ret = O.batchify_rays(sample_rays[:n], 4096, network_fn=net_c, network_query_fn=q, **kw)
-    dt = time.perf_counter() - t0
+    evals_per_ray = Sc + (Sc + Si if Si else 0)
+    probe = sample_rays[:: max(1, len(sample_rays) // 512)][:512]
+
+    def rate(rays, chunk=1024):
+        t0 = time.perf_counter()
+        O.batchify_rays(rays, chunk, network_fn=net_c, network_query_fn=q, **kw)
+        return len(rays) * evals_per_ray / (time.perf_counter() - t0)
+
+    ncpu = os.cpu_count() or 1
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [os.cpu_count()])
+        ncpu = min(ncpu, len(os.sched_getaffinity(0)))
     except Exception:
-        cores = os.cpu_count()
-    evals = n * (Sc + (Sc + Si if Si else 0))
-    return ret, n, {"value": evals / dt, "unit": "ray-samples/s", "cores": int(cores), "kind": "port",
-                    "sample": f"{n} rays of the same frame ({evals} MLP evals) in {dt:.1f} s, numpy/OpenBLAS "
-                              f"oracle on the host CPU ({os.cpu_count()} logical cores visible); "
-                              f"{n / dt:.0f} rays/s"}
+        pass
+    t_numpy = rate(probe[:128])                         # numpy/OpenBLAS backend, its own thread pool
+    O.set_gemm_backend("torch")
+    old_threads = torch.get_num_threads()
+    tried = {}
+    try:
+        rate(probe[:64])
+        for t in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}):
+            torch.set_num_threads(t)
+            tried[t] = rate(probe)
+        best = max(tried, key=tried.get)
+        torch.set_num_threads(best)
+        n = int(min(len(sample_rays), max(256, target_s * tried[best] / evals_per_ray)))
+        n = max(64, (n // 64) * 64)
+        t0 = time.perf_counter()
+        O.batchify_rays(sample_rays[:n], 1024, network_fn=net_c, network_query_fn=q, **kw)
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(old_threads)
+        O.set_gemm_backend("numpy")
+    evals = n * evals_per_ray
+    return {"value": evals / dt, "unit": "ray-samples/s", "cores": int(best), "kind": "port",
+            "per_core": evals / dt / best,
+            "threads_tried": {str(k): round(v) for k, v in tried.items()},
+            "numpy_openblas_backend": round(t_numpy),
+            "reference_pytorch_cpu_survey_container": "0.96e5-1.24e5 ray-samples/s on 8 threads (BASELINE.md section 2; other host)",
+            "sample": f"{n} rays of the same frame ({evals} MLP evals) in {dt:.1f} s: CPU oracle (numpy restatement, "
+                      f"GEMMs through PyTorch's CPU sgemm, 1024-ray chunks = 65536-point MLP batches) on {best} threads "
+                      f"of the host ({ncpu} logical cores usable), {n / dt:.0f} rays/s, {evals / dt / best:.0f} "
+                      f"ray-samples/s/core; numpy/OpenBLAS backend on the probe: {t_numpy:.0f} ray-samples/s; the "
+                      f"reference's own PyTorch-CPU path measured in the survey container: 0.96e5-1.24e5 on 8 threads"}
+
+
+def reference_parity(N, net_c, net_f, query):
+    """HIP render of the 4096 fixture rays of this frame against the REFERENCE's fp32 render of the same rays
+    (tests/golden/bench_frame.npz, generated by tests/golden/make_golden.py from the reference itself), with the
+    reference's own fp32-vs-fp64 flips beside it; criterion and definitions: oracle/parity.py."""
+    from oracle import parity
+    path = os.path.join(ROOT, "tests", "golden", "bench_frame.npz")
+    g = np.load(path)
+    rays = torch.from_numpy(g["rays"]).cuda()
+    kw = dict(N_samples=64, N_importance=128, network_fine=net_f, white_bkgd=True)
+    ex = {}
+    ret = N.render_rays(rays, net_c, query, _extras=ex, **kw)
+    z_fine = np.sort(np.concatenate([ex["z_coarse"].cpu().numpy(), g["z_samples"]], -1), -1)      # nerf.ipynb:467
+    inj = N.render_rays(rays, net_c, query, _z_vals_fine=z_fine, **kw)
+    got = {k: v.cpu().numpy() for k, v in ret.items()}
+    out = {"against": "reference fp32 render of 4096 rays of this frame (tests/golden/bench_frame.npz)",
+           "rgb0_linf": float(np.abs(got["rgb0"] - g["rgb0"]).max()),
+           "acc0_linf": float(np.abs(got["acc0"] - g["acc0"]).max())}
+    try:
+        st = parity.check_resampled(got, g, injected={k: v.cpu().numpy() for k, v in inj.items()}, fp64=g,
+                                    foreground=g["acc0"] > 1e-3)
+        out["criterion"] = "pass"
+    except AssertionError as e:                      # reported, not hidden: the numbers below are then partial
+        st = {}
+        out["criterion"] = "FAIL: " + str(e)[:300]
+    st.pop("flip_rays", None)
+    out.update(st)
+    mse = float(np.mean((got["rgb_map"] - g["rgb_map"]) ** 2))
+    out["psnr_vs_reference_db"] = float(-10 * np.log10(mse)) if mse > 0 else float("inf")
+    return out
+
+
+def train_leg(N, synthetic, iters=30, warmup=5, n_rand=1024, Sc=64, Si=128):
+    """Training iterations per second of the reference's loop body (nerf.ipynb:1258-1282) at N_rand = 1024, 64+128:
+    the same measurement as bench_train.py, short, after the timed region."""
+    sd_c, sd_f = synthetic.synthetic_pair(0)
+    mk = dict(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+    net_c, net_f = N.NeRF(**mk).load_state_dict(sd_c), N.NeRF(**mk).load_state_dict(sd_f)
+    opt = N.Adam([net_c, net_f], lr=5e-4, betas=(0.9, 0.999))
+    K, c2w, near, far = synthetic.lego_camera(800, 800)
+    packed = N.generate_rays(800, 800, K, c2w, ndc=False, near=near, far=far, use_viewdirs=True)
+    kw = dict(network_fn=net_c, network_fine=net_f, N_samples=Sc, N_importance=Si, white_bkgd=True, perturb=1.0,
+              raw_noise_std=1.0, ndc=False, use_viewdirs=True, near=near, far=far)
+    torch.manual_seed(0)
+
+    def one(i):
+        idx = torch.randperm(packed.shape[0], device="cuda")[:n_rand]
+        r = packed[idx]
+        target = torch.rand((n_rand, 3), device="cuda")
+        out = N.train_on_batch(800, 800, K, (r[:, 0:3], r[:, 3:6]), target, opt, **kw)
+        opt.param_groups[0]['lr'] = 5e-4 * (0.1 ** (i / 500000))
+        return out
+
+    for i in range(warmup):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        out = one(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    evals = n_rand * (Sc + Sc + Si)
+    tf = evals * FLOP_PER_EVAL * 3 * iters / dt / 1e12          # forward + dX + dW
+    return {"metric": "train_iterations_per_sec", "value": iters / dt, "unit": "it/s", "iters": iters,
+            "ms_per_iter": dt / iters * 1e3, "n_rand": n_rand, "N_samples": Sc, "N_importance": Si,
+            "tflops_effective": tf, "frac_of_fp32_mfma_peak": tf / PEAK_FP32_MFMA_TFLOPS,
+            "arithmetic": "f32 (v_mfma_f32_32x32x2_f32), fp32 master weights", "final_loss": float(out["loss"]),
+            "reference_stored_run": "5.6-7.4 it/s (ship 96+192, unknown CUDA GPU; BASELINE.md section 1)"}
 
 
 def pmc_traffic(precision):
@@ -137,12 +238,12 @@ def main():
     kw = dict(network_fn=net_c, network_query_fn=query, N_samples=Sc, N_importance=Si,
               network_fine=net_f if Si else None, white_bkgd=white, perturb=0., raw_noise_std=0.)
 
-    # inputs resident in HBM before the timed region: the packed ray record of this rank's shard
-    packed, sh = N.pack_rays(H, W, K, c2w=c2w, ndc=ndc, near=near, far=far, use_viewdirs=True, device="cuda")
-    n_total = packed.shape[0]
+    # inputs resident in HBM before the timed region: the packed ray record of this rank's shard, generated on this
+    # rank's GPU for its own pixel range only (nerf_generate_rays; no rank ever holds the whole frame)
+    n_total = H * W
     lo, hi = N.shard_bounds(n_total, world, rank)
-    shard = packed[lo:hi].contiguous()
-    del packed
+    shard = N.generate_rays(H, W, K, c2w, ndc=ndc, near=near, far=far, use_viewdirs=True, first_pixel=lo,
+                            n_pixels=hi - lo)
     evals_per_ray = Sc + (Sc + Si if Si else 0)
     ctx = N.get_context()
     if args.precision:
@@ -188,7 +289,7 @@ def main():
     else:
         mlp_ms_sum, pts_sum, launches_sum = mlp_ms, float(mlp_points), float(mlp_launches)
 
-    # the other arithmetic mode on the same rays, outside the timed region above: 1 warm-up + 2 timed frames,
+    # the other arithmetic mode on the same rays, outside the timed region above: 1 warm-up + 5 timed frames,
     # reported in `other_precision` so that both kernels' numbers come from one run
     other = None
     if not args.no_other_precision:
@@ -199,7 +300,8 @@ def main():
         ctx.profile_enable(True)
         ctx.profile_read(reset=True)
         t1 = time.perf_counter()
-        for _ in range(2):
+        n_alt = 5
+        for _ in range(n_alt):
             step()
         fence()
         dt_alt = time.perf_counter() - t1
@@ -212,8 +314,8 @@ def main():
         dt_alt = float(ta[0])
         a_tf = a_points / max(a_launches, 1) * FLOP_PER_EVAL / max(a_ms / max(a_launches, 1) * 1e-3, 1e-12) / 1e12
         a_peak = PEAK_FP32_MFMA_TFLOPS if alt == "f32" else PEAK_FP16_MFMA_TFLOPS / 3
-        other = {"precision": alt, "steps": 2, "ms_per_step": dt_alt / 2 * 1e3,
-                 "value": n_total * evals_per_ray * 2 / dt_alt, "unit": "ray-samples/s",
+        other = {"precision": alt, "steps": n_alt, "warmup": 1, "ms_per_step": dt_alt / n_alt * 1e3,
+                 "value": n_total * evals_per_ray * n_alt / dt_alt, "unit": "ray-samples/s",
                  "roofline": {"achieved": a_tf, "peak": a_peak, "frac": a_tf / a_peak, "unit": "TFLOP/s",
                               "avg_launch_ms": a_ms / max(a_launches, 1), "note": "rank 0's kernel time"}}
 
@@ -262,31 +364,20 @@ def main():
         }
         if other is not None:
             out["other_precision"] = other
+        out["precision_status"] = int(ctx.precision_status())      # layers whose a-priori scale bound was loose (0 = none)
+        if world == 1 and not args.no_train and not use_dist:
+            out["train"] = train_leg(N, synthetic)
         if world == 1 and not args.no_cpu_baseline:
+            if args.workload == "lego_800x800_64c+128f":
+                out["parity"] = reference_parity(N, net_c, net_f, query)
             # same rays, spread over the whole frame so empty, grazing and opaque rays are all present
             idx = np.linspace(0, n_total - 1, 4096).astype(np.int64)
             sample = shard[torch.from_numpy(idx).cuda()].cpu().numpy()
-            ref, n_used, cb = cpu_baseline(sample, sd_c, sd_f, Sc, Si, white, args.cpu_seconds)
-            out["cpu_baseline"] = cb
-            got = frame["rgb_map"][torch.from_numpy(idx[:n_used]).cuda()].cpu().numpy()
-            err = np.abs(got - ref["rgb_map"]).max(-1)
-            mse = float(np.mean((got - ref["rgb_map"]) ** 2))
-            out["parity"] = {"rays": int(n_used), "rgb_linf": float(err.max()), "rgb_p99": float(np.quantile(err, .99)),
-                             "rgb_median": float(np.median(err)), "rays_above_1e-4": int((err > 1e-4).sum()),
-                             "psnr_vs_cpu_oracle_db": (float(-10 * np.log10(mse)) if mse > 0 else float("inf"))}
-            if Si:
-                e0 = np.abs(frame_rgb0(N, shard, idx[:n_used], kw) - ref["rgb0"]).max()
-                out["parity"]["rgb0_linf"] = float(e0)
+            out["cpu_baseline"] = cpu_baseline(sample, sd_c, sd_f, Sc, Si, white, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def frame_rgb0(N, shard, idx, kw):
-    """Coarse-pass colours of the sampled rays (the well-conditioned half of the parity report)."""
-    rays = shard[torch.from_numpy(idx).cuda()].contiguous()
-    return N.batchify_rays(rays, 32768, **kw)["rgb0"].cpu().numpy()
 
 
 if __name__ == "__main__":

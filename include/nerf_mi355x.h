@@ -249,6 +249,21 @@ typedef struct nerf_frame_args {
 
 int nerf_render_frame(nerf_ctx* ctx, const nerf_frame_args* args);
 
+/* Multi-GPU frame rendering (the `render_sharded` entry of section 8b's export list).
+ * The reference's nerf/ path is single-device; rays are independent and cost the same, so the flat [H*W] pixel index is
+ * cut into `world` contiguous shards (the first n_total % world ranks get one pixel more) and every rank - one process
+ * and one nerf_ctx per GPU - renders its shard with no data-path collective:
+ *   nerf_shard_bounds   the partition rule: rank owns [*first_pixel, *first_pixel + *n_pixels)
+ *   nerf_render_shard   nerf_render_frame for that range: `args->first_pixel / n_pixels` are ignored and the range of
+ *                       (world, rank) is used; outputs are [n_pixels of the shard, ...]; the range is returned through
+ *                       first_pixel / n_pixels (may be NULL). An empty shard (n_total < world) renders nothing.
+ * The one exchange per frame - gathering rgb|disp|acc (20 B/ray) to rank 0 - belongs to the host's collective library
+ * (RCCL ncclGather / torch.distributed.gather on the same stream; INTEGRATION.md shows both): this library links
+ * libamdhip64 only. nerf_render_frame(first_pixel, n_pixels) itself is the C-level shard call for any other partition. */
+int nerf_shard_bounds(int64_t n_total, int world, int rank, int64_t* first_pixel, int64_t* n_pixels);
+int nerf_render_shard(nerf_ctx* ctx, const nerf_frame_args* args, int world, int rank, int64_t* first_pixel,
+                      int64_t* n_pixels);
+
 /* Image metrics -----------------------------------------------------
  * calculate_ssim (nerf/nerf_helpers.py:21-111): separable 11-tap Gaussian (sigma 1.5), zero padded,
  * on [H,W,3] images clamped to [0,max_val]; img2mse (nerf_helpers.py:8). Results are written to

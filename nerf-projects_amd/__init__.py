@@ -9,7 +9,7 @@ from . import synthetic  # noqa: F401
 from .host import (Adam, NeRF, NetworkQuery, train_on_batch, batchify, batchify_rays, calculate_lpips, calculate_metrics,  # noqa: F401
                    calculate_ssim, create_nerf, generate_rays, get_context, get_embedder, get_rays, get_rays_np,
                    img2mse, load_checkpoint, make_network_query_fn, mse2psnr, ndc_rays, pack_rays, raw2outputs,
-                   render, render_path, render_rays, run_network, sample_pdf, save_checkpoint, to8b, write_png)
+                   render, render_path, render_rays, render_shard, run_network, sample_pdf, save_checkpoint, to8b, write_png)
 from . import datasets  # noqa: F401
 from .datasets import load_blender_data, load_llff_data, read_png  # noqa: F401
 from .sharded import gather_frame, render_sharded, shard_bounds  # noqa: F401

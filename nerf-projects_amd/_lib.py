@@ -19,6 +19,7 @@ EXPORTS = (
     "nerf_workspace_bytes", "nerf_generate_rays", "nerf_image_metrics", "nerf_train_step", "nerf_get_weights",
     "nerf_get_gradients", "nerf_stratified_z", "nerf_resample", "nerf_render_frame", "nerf_set_precision",
     "nerf_get_precision", "nerf_precision_status", "nerf_get_adam_state", "nerf_set_adam_state",
+    "nerf_shard_bounds", "nerf_render_shard",
 )
 
 
@@ -130,6 +131,10 @@ def load():
     lib.nerf_resample.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp]
     lib.nerf_render_frame.restype = i32
     lib.nerf_render_frame.argtypes = [vp, C.POINTER(FrameArgs)]
+    lib.nerf_shard_bounds.restype = i32
+    lib.nerf_shard_bounds.argtypes = [i64, i32, i32, C.POINTER(i64), C.POINTER(i64)]
+    lib.nerf_render_shard.restype = i32
+    lib.nerf_render_shard.argtypes = [vp, C.POINTER(FrameArgs), i32, i32, C.POINTER(i64), C.POINTER(i64)]
     lib.nerf_workspace_bytes.restype = i64
     lib.nerf_workspace_bytes.argtypes = [vp]
     lib.nerf_set_precision.restype = i32

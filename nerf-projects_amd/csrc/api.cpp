@@ -668,6 +668,34 @@ int nerf_render_frame(nerf_ctx* c, const nerf_frame_args* f) {
     return NERF_OK;
 }
 
+int nerf_shard_bounds(int64_t n_total, int world, int rank, int64_t* first_pixel, int64_t* n_pixels) {
+    if (n_total < 0 || world <= 0 || rank < 0 || rank >= world || !first_pixel || !n_pixels) {
+        set_error("nerf_shard_bounds: invalid argument (n_total %lld, world %d, rank %d)", (long long)n_total, world, rank);
+        return NERF_E_INVALID;
+    }
+    const int64_t base = n_total / world, rem = n_total % world;
+    *first_pixel = rank * base + (rank < rem ? rank : rem);
+    *n_pixels = base + (rank < rem ? 1 : 0);
+    return NERF_OK;
+}
+
+int nerf_render_shard(nerf_ctx* c, const nerf_frame_args* f, int world, int rank, int64_t* first_pixel,
+                      int64_t* n_pixels) {
+    if (!c || !f || f->cam.H <= 0 || f->cam.W <= 0) {
+        set_error("nerf_render_shard: invalid argument");
+        return NERF_E_INVALID;
+    }
+    int64_t lo = 0, n = 0;
+    const int rc = nerf_shard_bounds((int64_t)f->cam.H * f->cam.W, world, rank, &lo, &n);
+    if (rc != NERF_OK) return rc;
+    if (first_pixel) *first_pixel = lo;
+    if (n_pixels) *n_pixels = n;
+    nerf_frame_args shard = *f;
+    shard.first_pixel = lo;
+    shard.n_pixels = n;
+    return nerf_render_frame(c, &shard);
+}
+
 int nerf_image_metrics(nerf_ctx* c, const float* img1, const float* img2, int H, int W, float max_val, float* out,
                        void* stream) {
     if (!c || !img1 || !img2 || !out || H <= 0 || W <= 0) {

@@ -117,14 +117,26 @@ struct Pending {
     float m;       // running max |y|
 };
 
+// NERF_V2_ACCREAD: the pending layer's sums stay in the accumulator registers they were produced in and are fetched
+// one pair per step (v_accvgpr_read in the MFMA shadow) instead of 128 at the layer boundary
+__device__ __forceinline__ float acc_get(const float& a) {
+#ifdef NERF_V2_ACCREAD
+    float v;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+    return v;
+#else
+    return a;
+#endif
+}
+
 template <int P>
 __device__ __forceinline__ void convert_pair(XT& dst, const f32x16& src, Pending& pd, const f32x2& b) {
 #ifdef NERF_ABLATE_CONV
     if (P == 0) dst.hi[0][0] = __float_as_uint(src[0] + b[0]);
     return;
 #endif
-    const float y0 = fmaxf(fmaf(src[2 * P], pd.c, b[0]), pd.floor);
-    const float y1 = fmaxf(fmaf(src[2 * P + 1], pd.c, b[1]), pd.floor);
+    const float y0 = fmaxf(fmaf(acc_get(src[2 * P]), pd.c, b[0]), pd.floor);
+    const float y1 = fmaxf(fmaf(acc_get(src[2 * P + 1]), pd.c, b[1]), pd.floor);
     pd.m = fmaxf(fmaxf(pd.m, fabsf(y0)), fabsf(y1));
     const float a0 = y0 * pd.sc, a1 = y1 * pd.sc;
     const unsigned hi = __builtin_bit_cast(unsigned, round_pair(a0, a1));
@@ -158,8 +170,8 @@ __device__ __forceinline__ void conv_slice0(ConvTmp& t, const f32x16& src, const
     t.y0 = src[2 * P] + b[0]; t.y1 = 0.0f;
     return;
 #endif
-    t.y0 = fmaxf(fmaf(src[2 * P], pd.c, b[0]), pd.floor);
-    t.y1 = fmaxf(fmaf(src[2 * P + 1], pd.c, b[1]), pd.floor);
+    t.y0 = fmaxf(fmaf(acc_get(src[2 * P]), pd.c, b[0]), pd.floor);
+    t.y1 = fmaxf(fmaf(acc_get(src[2 * P + 1]), pd.c, b[1]), pd.floor);
 }
 __device__ __forceinline__ void conv_slice1(ConvTmp& t, Pending& pd) {
 #ifdef NERF_ABLATE_CONV

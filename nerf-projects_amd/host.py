@@ -744,8 +744,13 @@ def generate_rays(H, W, K, c2w, ndc=True, near=0., far=1., use_viewdirs=False, c
 
 
 def _render_frame_fused(ctx, cam, first_pixel, n_pixels, chunk, net_c, net_f, N_samples, N_importance, lindisp,
-                        white_bkgd):
-    """One ``nerf_render_frame`` call: ray generation + chunk loop + render_rays, nothing but kernels enqueued."""
+                        white_bkgd, shard=None):
+    """One ``nerf_render_frame`` call: ray generation + chunk loop + render_rays, nothing but kernels enqueued.
+    With ``shard = (world, rank)`` the pixel range is the rank's shard and the call is ``nerf_render_shard``."""
+    if shard is not None:
+        lo, cnt = C.c_int64(), C.c_int64()
+        check(ctx.lib.nerf_shard_bounds(int(cam.H) * int(cam.W), int(shard[0]), int(shard[1]), C.byref(lo), C.byref(cnt)))
+        first_pixel, n_pixels = lo.value, cnt.value
     o = dict(device=ctx.device, dtype=torch.float32)
     ret = {"rgb_map": torch.empty((n_pixels, 3), **o), "disp_map": torch.empty((n_pixels,), **o),
            "acc_map": torch.empty((n_pixels,), **o)}
@@ -760,8 +765,31 @@ def _render_frame_fused(ctx, cam, first_pixel, n_pixels, chunk, net_c, net_f, N_
                    acc0=torch.empty((n_pixels,), **o), z_std=torch.empty((n_pixels,), **o))
         f.rgb0, f.disp0, f.acc0, f.z_std = (ret[k].data_ptr() for k in ("rgb0", "disp0", "acc0", "z_std"))
     f.stream = ctx.stream().value
-    check(ctx.lib.nerf_render_frame(ctx.handle, C.byref(f)))
+    if shard is not None:
+        check(ctx.lib.nerf_render_shard(ctx.handle, C.byref(f), int(shard[0]), int(shard[1]), None, None))
+    else:
+        check(ctx.lib.nerf_render_frame(ctx.handle, C.byref(f)))
     return ret
+
+
+def render_shard(H, W, K, world, rank, chunk=1024 * 32, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+                 c2w_staticcam=None, first_pixel=None, n_pixels=None, **kwargs):
+    """Rank ``rank``'s contiguous shard of ``render(H, W, K, chunk, c2w=c2w, ...)`` (deterministic kwargs,
+    ``render_kwargs_test``): one ``nerf_render_shard`` call - the rank generates and renders only its own pixels.
+    Returns the flat ``{rgb_map, disp_map, acc_map, (rgb0, disp0, acc0, z_std)}`` dict of ``[n_shard, ...]`` tensors;
+    row i is flat pixel ``shard_bounds(H*W, world, rank)[0] + i``. An explicit ``first_pixel`` / ``n_pixels`` range
+    (any partition) goes through ``nerf_render_frame`` instead."""
+    if c2w is None or not _frame_call_applies(kwargs) or \
+            not kwargs['network_query_fn'].matches(kwargs['network_fn'], bool(use_viewdirs)):
+        raise RuntimeError("render_shard needs c2w, this package's networks / NetworkQuery and deterministic kwargs "
+                           "(perturb = 0, raw_noise_std = 0, retraw = False)")
+    net = kwargs['network_fn']
+    cam = _camera(H, W, K, c2w, ndc, near, far, use_viewdirs, c2w_staticcam)
+    args = (chunk, net, kwargs.get('network_fine'), kwargs['N_samples'], kwargs.get('N_importance', 0),
+            kwargs.get('lindisp', False), kwargs.get('white_bkgd', False))
+    if first_pixel is not None:
+        return _render_frame_fused(net.ctx, cam, int(first_pixel), int(n_pixels), *args)
+    return _render_frame_fused(net.ctx, cam, 0, 0, *args, shard=(world, rank))
 
 
 def _frame_call_applies(kwargs):

@@ -60,6 +60,12 @@ def gather_frame(local, n_total, group=None, dst=0, force_collective=False):
     return out
 
 
+def _empty_outputs(shard, keys, kwargs):
+    """What ``batchify_rays`` would return for zero rays if it knew the per-ray shapes (it returns ``{}``)."""
+    widths = {"rgb_map": (3,), "rgb0": (3,)}
+    return {k: torch.zeros((0,) + widths.get(k, ()), dtype=torch.float32, device=shard.device) for k in keys}
+
+
 def render_sharded(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
                    c2w_staticcam=None, group=None, keys=("rgb_map", "disp_map", "acc_map"), render_chunks=None,
                    **kwargs):
@@ -78,18 +84,29 @@ def render_sharded(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near
     device = None
     if 'network_fn' in kwargs and hasattr(kwargs['network_fn'], 'parameters'):
         device = next(kwargs['network_fn'].parameters()).device
-    if c2w is not None and isinstance(kwargs.get('network_fn'), host.NeRF):
-        # each rank generates only its own shard of the frame's rays, on its GPU
+    fused = (render_chunks is host.batchify_rays and c2w is not None and host._frame_call_applies(kwargs)
+             and kwargs['network_query_fn'].matches(kwargs['network_fn'], bool(use_viewdirs))
+             and all(k in ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std") for k in keys))
+    if fused:
+        # one C call per rank and frame (nerf_render_shard): the rank generates and renders only its own pixels
         n_total, sh = int(H) * int(W), (H, W, 3)
-        lo, hi = shard_bounds(n_total, world, rank)
-        shard = host.generate_rays(H, W, K, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, first_pixel=lo,
-                                   n_pixels=hi - lo, device=device)
+        ret = host.render_shard(H, W, K, world, rank, chunk, c2w=c2w, ndc=ndc, near=near, far=far,
+                                use_viewdirs=use_viewdirs, c2w_staticcam=c2w_staticcam, **kwargs)
     else:
-        packed, sh = host.pack_rays(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, device=device)
-        n_total = packed.shape[0]
-        lo, hi = shard_bounds(n_total, world, rank)
-        shard = packed[lo:hi]
-    ret = render_chunks(shard, chunk, **kwargs)
+        if c2w is not None and isinstance(kwargs.get('network_fn'), host.NeRF):
+            # each rank generates only its own shard of the frame's rays, on its GPU
+            n_total, sh = int(H) * int(W), (H, W, 3)
+            lo, hi = shard_bounds(n_total, world, rank)
+            shard = host.generate_rays(H, W, K, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, first_pixel=lo,
+                                       n_pixels=hi - lo, device=device)
+        else:
+            packed, sh = host.pack_rays(H, W, K, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, device=device)
+            n_total = packed.shape[0]
+            lo, hi = shard_bounds(n_total, world, rank)
+            shard = packed[lo:hi]
+        ret = render_chunks(shard, chunk, **kwargs)
+        if not ret:                                  # a rank with an empty shard (n_total < world): shaped empties
+            ret = _empty_outputs(shard, keys, kwargs)
     local = {k: ret[k] for k in keys}
     if world == 1:
         full = local

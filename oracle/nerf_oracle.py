@@ -21,6 +21,19 @@ import numpy as np
 
 F32 = np.float32
 
+# GEMM backend of NeRF._linear. "numpy" (default: the pinned checker, whatever BLAS numpy links) or "torch":
+# torch.addmm on CPU tensors sharing the numpy buffers - the same y = x W^T + b through PyTorch's CPU sgemm, i.e. the
+# BLAS the reference itself runs on. Used by bench.py's cpu_baseline leg only, so that the reported CPU rate is not
+# held back by numpy's OpenBLAS build (2.5x slower here at equal threads); tests/test_oracle_golden.py checks that
+# the two backends agree to rounding.
+_GEMM = {"backend": "numpy"}
+
+
+def set_gemm_backend(name):
+    if name not in ("numpy", "torch"):
+        raise ValueError(name)
+    _GEMM["backend"] = name
+
 
 # ----------------------------------------------------------------------------------------------
 # helpers that restate torch semantics the reference relies on
@@ -71,7 +84,7 @@ def get_embedder(multires, i=0):
             xf = x * f
             parts.append(np.sin(xf))
             parts.append(np.cos(xf))
-        return np.concatenate(parts, axis=-1).astype(F32)
+        return np.concatenate(parts, axis=-1).astype(F32, copy=False)
 
     return embed, 3 + 6 * multires
 
@@ -105,7 +118,12 @@ class NeRF:
         return self.sd
 
     def _linear(self, name, x):
-        return (x @ self.sd[name + ".weight"].T + self.sd[name + ".bias"]).astype(F32)
+        if _GEMM["backend"] == "torch":
+            import torch
+            xt = torch.from_numpy(np.ascontiguousarray(x, dtype=F32))
+            y = torch.addmm(torch.from_numpy(self.sd[name + ".bias"]), xt, torch.from_numpy(self.sd[name + ".weight"]).t())
+            return y.numpy()
+        return (x @ self.sd[name + ".weight"].T + self.sd[name + ".bias"]).astype(F32, copy=False)
 
     def __call__(self, x):
         return self.forward(x)
@@ -298,7 +316,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     """The per-ray-chunk renderer. ``_extras`` (a dict) receives intermediates
     (coarse/fine z_vals, weights); ``_inject`` may carry explicit random arrays
     ``t_rand`` [N,S_c], ``u`` [N,S_i], ``noise0`` [N,S_c], ``noise`` [N,S_c+S_i]
-    so that perturbed paths can be compared without sharing an RNG."""
+    so that perturbed paths can be compared without sharing an RNG, and ``z_fine`` [N,S_c+S_i]: fine depths to
+    evaluate the fine pass at (in place of the merged ones; z_std still describes the own samples)."""
     inj = _inject or {}
     ray_batch = np.asarray(ray_batch, dtype=F32)
     N_rays = ray_batch.shape[0]
@@ -339,6 +358,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         z_samples = sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance,
                                det=(perturb == 0.), pytest=pytest, u=inj.get("u"))  # :462
         z_vals = np.sort(np.concatenate([z_vals, z_samples], -1), -1)               # :467
+        if "z_fine" in inj:                      # parity tests: evaluate the fine pass at given depths
+            z_vals = np.ascontiguousarray(inj["z_fine"], dtype=F32)
         pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]    # :468
         run_fn = network_fn if network_fine is None else network_fine               # :471
         raw = network_query_fn(pts, viewdirs, run_fn)                               # :473

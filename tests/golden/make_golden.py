@@ -296,16 +296,20 @@ def gold_render_rays():
     save("lego_frame_rays", pix=corner, rays=all_rays[corner], K=K, c2w=c2w)
 
     # same rays: fine pass reusing the coarse net (network_fine=None), lindisp, no white bkgd
-    ret2, _ = capture_render_rays(rays[:64], net_c, None, N_samples=64, N_importance=64, lindisp=True,
-                                  white_bkgd=False, perturb=0., raw_noise_std=0.)
-    save("render_rays_lindisp", rays=rays[:64], **ret2)
+    kwl = dict(N_samples=64, N_importance=64, lindisp=True, white_bkgd=False, perturb=0., raw_noise_std=0.)
+    ret2, rec2 = capture_render_rays(rays[:64], net_c, None, **kwl)
+    ret2_64, _ = capture_render_rays(rays[:64], net_c64, None, dtype=torch.float64, **kwl)
+    save("render_rays_lindisp", rays=rays[:64], z_fine=rec2["r2o"][1]["z_vals"], **ret2,
+         **{k + "_fp64": v.astype(np.float64) for k, v in ret2_64.items()})
 
     # perturbed / noisy path with the reference's pytest RNG (np.random.seed(0) before every draw)
     kwp = dict(N_samples=64, N_importance=128, retraw=False, white_bkgd=True, perturb=1.0,
                raw_noise_std=1.0, pytest=True)
     retp, recp = capture_render_rays(rays[:32], net_c, net_f, **kwp)
+    retp64, _ = capture_render_rays(rays[:32], net_c64, net_f64, dtype=torch.float64, **kwp)
     save("render_rays_perturb", rays=rays[:32], z_coarse=recp["r2o"][0]["z_vals"],
-         z_samples=recp["pdf"][0], z_fine=recp["r2o"][1]["z_vals"], **retp)
+         z_samples=recp["pdf"][0], z_fine=recp["r2o"][1]["z_vals"], **retp,
+         **{k + "_fp64": v.astype(np.float64) for k, v in retp64.items()})
 
     # C4-like: NDC rays of a forward-facing camera, 256 rays, 64+128, no white bkgd
     K, c2w, near, far = synthetic.fern_camera()
@@ -320,6 +324,34 @@ def gold_render_rays():
          **{k + "_fp64": v.astype(np.float64) for k, v in retn64.items()})
 
 
+def gold_bench_frame():
+    """The 4096 rays bench.py's parity leg samples from the 800x800 lego frame (np.linspace over the flat ray
+    index), 64+128, rendered by the reference in fp32 AND in fp64: the reference-anchored end-to-end fixture at bench
+    scale. Stores the reference's packed rays (its own get_rays), every map of the return dict, the fine depths
+    (as the 128 new samples: z_fine = sort(cat[z_coarse, z_samples]), nerf.ipynb:467) and the fp64 twins."""
+    net_c, net_f = ref_pair(0)
+    net_c64, net_f64 = ref_pair(0, torch.float64)
+    K, c2w, near, far = synthetic.lego_camera(800, 800)
+    pix = np.linspace(0, 800 * 800 - 1, 4096).astype(np.int64)
+    rays = reference_pack(800, 800, K, c2w, False, near, far, pix)
+    kw = dict(N_samples=64, N_importance=128, retraw=False, white_bkgd=True, perturb=0., raw_noise_std=0.)
+    ret, rec = {}, {"z_samples": []}
+    ret64 = {}
+    for i in range(0, len(rays), 1024):
+        r, c = capture_render_rays(rays[i:i + 1024], net_c, net_f, **kw)
+        r64, _ = capture_render_rays(rays[i:i + 1024], net_c64, net_f64, dtype=torch.float64, **kw)
+        for k, v in r.items():
+            ret.setdefault(k, []).append(v)
+        for k, v in r64.items():
+            ret64.setdefault(k, []).append(v)
+        rec["z_samples"].append(c["pdf"][0])
+        print(f"    bench_frame rays {i + 1024}/{len(rays)}", flush=True)
+    ret = {k: np.concatenate(v, 0) for k, v in ret.items()}
+    ret64 = {k: np.concatenate(v, 0) for k, v in ret64.items()}
+    save("bench_frame", pix=pix, rays=rays, z_samples=np.concatenate(rec["z_samples"], 0), **ret,
+         **{k + "_fp64": v.astype(np.float64) for k, v in ret64.items()})
+
+
 def gold_render():
     """render() end to end on a tiny 12x10 image (both tuple rays and c2w), chunked unevenly."""
     net_c, net_f = ref_pair(0)
@@ -330,10 +362,35 @@ def gold_render():
     c2w = synthetic.pose_spherical(30.0, -30.0, 4.0)[:3, :4]
     kwargs = dict(network_fn=net_c, network_fine=net_f, network_query_fn=query_fn(e_fn, ed_fn),
                   N_samples=16, N_importance=16, white_bkgd=True, perturb=0., raw_noise_std=0.)
-    with torch.no_grad():
-        rgb, disp, acc, extras = NS["render"](H, W, K, chunk=50, c2w=torch.from_numpy(c2w), ndc=False,
-                                              near=2., far=6., use_viewdirs=True, **kwargs)
-    save("render_small", H=H, W=W, K=K, c2w=c2w, rgb=n(rgb), disp=n(disp), acc=n(acc),
+    z_calls = []
+    orig_r2o = NS["raw2outputs"]
+
+    def r2o(raw, z_vals, *a, **k):
+        z_calls.append(n(z_vals))
+        return orig_r2o(raw, z_vals, *a, **k)
+
+    NS["raw2outputs"] = r2o
+    try:
+        with torch.no_grad():
+            rgb, disp, acc, extras = NS["render"](H, W, K, chunk=50, c2w=torch.from_numpy(c2w), ndc=False,
+                                                  near=2., far=6., use_viewdirs=True, **kwargs)
+    finally:
+        NS["raw2outputs"] = orig_r2o
+    z_fine = np.concatenate(z_calls[1::2], 0)           # per chunk: coarse call, then fine call
+    # the reference's own fp64 render of the same frame (conditioning floor of the resampled output)
+    net_c64, net_f64 = ref_pair(0, torch.float64)
+    kw64 = dict(kwargs, network_fn=net_c64, network_fine=net_f64)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        with torch.no_grad():
+            rgb64, disp64, acc64, extras64 = NS["render"](H, W, K, chunk=50, c2w=torch.from_numpy(c2w).double(), ndc=False,
+                                                   near=2., far=6., use_viewdirs=True, **kw64)
+    finally:
+        torch.set_default_dtype(old)
+    save("render_small", H=H, W=W, K=K, c2w=c2w, rgb=n(rgb), disp=n(disp), acc=n(acc), z_fine=z_fine,
+         rgb_fp64=n(rgb64).astype(np.float64), acc_fp64=n(acc64).astype(np.float64),
+         disp_fp64=n(disp64).astype(np.float64), z_std_fp64=n(extras64["z_std"]).astype(np.float64),
          **{k: n(v) for k, v in extras.items()})
 
 
@@ -527,12 +584,17 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     print("writing fixtures to", HERE)
+    if len(sys.argv) > 1:                       # python make_golden.py bench_frame render ...: only those
+        for name in sys.argv[1:]:
+            globals()["gold_" + name]()
+        sys.exit(0)
     gold_linspace()
     gold_embed()
     gold_mlp()
     gold_raw2outputs()
     gold_sample_pdf()
     gold_render_rays()
+    gold_bench_frame()
     gold_render()
     gold_ray_packing()
     gold_metrics()

@@ -8,7 +8,7 @@ fp32 stage-wise bar of SURVEY.md section 7 (~1e-6) unless noted.
 import numpy as np
 import pytest
 
-from conftest import check_end_to_end, check_sample_pdf, load_golden
+from conftest import check_resampled, check_sample_pdf, load_golden
 from nerf_projects_amd import synthetic
 from oracle import nerf_oracle as O
 
@@ -165,7 +165,27 @@ def test_render_rays_end_to_end(weights_pair, name, kw):
     assert set(ret) == {"rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"}
     for k in ("rgb0", "acc0"):
         assert np.abs(ret[k] - g[k]).max() <= 5e-6, k
-    check_end_to_end(ret["rgb_map"], g["rgb_map"], g["rgb_map_fp64"])
+    inj = O.render_rays(g["rays"], net_c, q, network_fine=net_f, perturb=0., raw_noise_std=0.,
+                        _inject={"z_fine": g["z_fine"]}, **kw)
+    check_resampled(ret, g, injected=inj, fp64=g, foreground=g["acc0"] > 1e-3)
+
+
+def test_render_rays_bench_scale(weights_pair):
+    """The 4096 rays of the 800x800 lego frame that bench.py's parity leg samples: the oracle against the reference's
+    own fp32 render, anchored on the reference's fp32-vs-fp64 behaviour on the same rays (tests/golden/bench_frame.npz;
+    every 4th ray here to keep the CPU suite short - the GPU test and bench.py use all 4096)."""
+    g = load_golden("bench_frame")
+    net_c, net_f, q = _oracle_nets(weights_pair)
+    kw = dict(N_samples=64, N_importance=128, network_fine=net_f, white_bkgd=True)
+    sub = {k: g[k][::4] for k in g.files}
+    ex = {}
+    ret = O.render_rays(sub["rays"], net_c, q, _extras=ex, **kw)
+    z_fine = np.sort(np.concatenate([ex["z_coarse"], sub["z_samples"]], -1), -1)       # nerf.ipynb:467
+    inj = O.render_rays(sub["rays"], net_c, q, _inject={"z_fine": z_fine}, **kw)
+    for k in ("rgb0", "acc0"):
+        assert np.abs(ret[k] - sub[k]).max() <= 5e-6, k
+    st = check_resampled(ret, sub, injected=inj, fp64=sub, foreground=sub["acc0"] > 1e-3)
+    assert st["foreground_rays"] > 300 and st["rgb_fg_median"] <= 2e-6
 
 
 def test_render_rays_variants(weights_pair):
@@ -175,7 +195,8 @@ def test_render_rays_variants(weights_pair):
                         white_bkgd=False, network_fine=None)
     for k in ("rgb0", "acc0", "disp0"):
         _close(ret[k], g[k], atol=5e-6, rtol=1e-5)
-    check_end_to_end(ret["rgb_map"], g["rgb_map"])
+    kwl = dict(N_samples=64, N_importance=64, lindisp=True, white_bkgd=False, network_fine=None)
+    check_resampled(ret, g, injected=O.render_rays(g["rays"], net_c, q, _inject={"z_fine": g["z_fine"]}, **kwl), fp64=g)
     g = load_golden("render_rays_perturb")
     ex = {}
     ret = O.render_rays(g["rays"], net_c, q, N_samples=64, N_importance=128, white_bkgd=True,
@@ -187,7 +208,9 @@ def test_render_rays_variants(weights_pair):
     check_sample_pdf(ex["z_samples"], g["z_samples"], mids, ex["weights_coarse"][:, 1:-1], u, atol=2e-5)
     for k in ("rgb0", "acc0"):
         assert np.abs(ret[k] - g[k]).max() <= 1e-5, k
-    check_end_to_end(ret["rgb_map"], g["rgb_map"])
+    inj = O.render_rays(g["rays"], net_c, q, N_samples=64, N_importance=128, white_bkgd=True, network_fine=net_f,
+                        perturb=1.0, raw_noise_std=1.0, pytest=True, _inject={"z_fine": g["z_fine"]})
+    check_resampled(ret, g, injected=inj, fp64=g)
 
 
 def test_render_small_frame(weights_pair):
@@ -201,7 +224,10 @@ def test_render_small_frame(weights_pair):
     assert rgb.shape == (H, W, 3) and disp.shape == (H, W) and acc.shape == (H, W)
     assert set(extras) == {"rgb0", "disp0", "acc0", "z_std"}
     assert np.abs(extras["rgb0"] - g["rgb0"]).max() <= 5e-6
-    check_end_to_end(rgb.reshape(-1, 3), g["rgb"].reshape(-1, 3))
+    packed, _ = O.pack_rays(H, W, g["K"], c2w=g["c2w"], ndc=False, near=2., far=6., use_viewdirs=True)
+    inj = O.render_rays(packed, net_c, q, network_fine=net_f, N_samples=16, N_importance=16, white_bkgd=True,
+                        _inject={"z_fine": g["z_fine"]})
+    check_resampled(dict(rgb=rgb, disp=disp, acc=acc, z_std=extras["z_std"]), g, injected=inj, fp64=g)
     # chunk independence
     rgb2 = O.render(H, W, g["K"], chunk=7, c2w=g["c2w"], ndc=False, near=2., far=6., use_viewdirs=True,
                     network_fn=net_c, network_fine=net_f, network_query_fn=q, N_samples=16,
@@ -244,3 +270,20 @@ def test_image_metrics():
     assert abs(m["psnr"] - float(g["psnr"])) <= 1e-4
     assert abs(m["ssim"] - float(g["ssim"])) <= 2e-5      # sigma = E[x^2]-mu^2 cancels; c2 = 9e-4 amplifies fp32 rounding
     assert abs(O.calculate_ssim(g["img1"], g["img1"]) - float(g["ssim_same"])) <= 2e-6
+
+
+def test_gemm_backends_agree(weights_pair):
+    """bench.py's cpu_baseline leg times the oracle with PyTorch's CPU sgemm under NeRF._linear (the BLAS the reference
+    itself runs on); same restatement, same result to rounding."""
+    g = load_golden("mlp_forward")
+    net = O.NeRF(8, 256, 63, 27, 4, (4,), True, synthetic.synthetic_state_dict(7))
+    a = net(g["embedded"])
+    O.set_gemm_backend("torch")
+    try:
+        b = net(g["embedded"])
+    finally:
+        O.set_gemm_backend("numpy")
+    scale = np.abs(g["out"]).max()
+    assert np.abs(a - b).max() <= 3e-6 * scale and np.abs(b - g["out"]).max() <= 3e-6 * scale
+    with pytest.raises(ValueError):
+        O.set_gemm_backend("cupy")

@@ -25,6 +25,22 @@ def test_shard_bounds_partition():
     assert shard_bounds(640000, 8, 3) == (240000, 320000)      # 100 image rows per GPU at 800x800
 
 
+def test_shard_bounds_c_abi_agrees():
+    """nerf_shard_bounds (include/nerf_mi355x.h) is the same partition rule as the Python one; bad arguments are errors."""
+    import ctypes as C
+    from nerf_projects_amd import _lib, shard_bounds
+    lib = _lib.load()
+    for n, w in ((640000, 8), (762048, 8), (10, 3), (7, 8), (0, 2), (120, 1), (5, 6)):
+        for r in range(w):
+            lo, cnt = C.c_int64(), C.c_int64()
+            assert lib.nerf_shard_bounds(n, w, r, C.byref(lo), C.byref(cnt)) == 0
+            assert (lo.value, lo.value + cnt.value) == shard_bounds(n, w, r)
+    lo, cnt = C.c_int64(), C.c_int64()
+    assert lib.nerf_shard_bounds(10, 0, 0, C.byref(lo), C.byref(cnt)) != 0
+    assert lib.nerf_shard_bounds(10, 2, 2, C.byref(lo), C.byref(cnt)) != 0
+    assert lib.nerf_shard_bounds(10, 2, 0, None, None) != 0 and b"nerf_shard_bounds" in lib.nerf_last_error()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -79,7 +95,7 @@ def test_gather_frame_single_process_with_empty_fields():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("H,W", [(6, 8), (5, 7)])          # even and uneven (35 rays over 2 ranks)
+@pytest.mark.parametrize("H,W", [(6, 8), (5, 7), (1, 1)])   # even, uneven (35 rays over 2 ranks), and an EMPTY shard on rank 1
 def test_two_rank_gloo_render(H, W):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
