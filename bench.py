@@ -56,7 +56,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--workload", default="lego_800x800_64c+128f", choices=sorted(WORKLOADS))
     p.add_argument("--chunk", type=int, default=32768)
-    p.add_argument("--precision", default=None, choices=["f16x2", "f32", "f16x2_s16"],
+    p.add_argument("--precision", default=None, choices=["f16x2", "f32"],
                    help="arithmetic of the fused MLP kernel (default: the library's, f16x2)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     p.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline and parity)")
@@ -330,9 +330,8 @@ def main():
         if precision.startswith("f16x2"):
             products = 3          # W_lo*x_hi + W_hi*x_lo + W_hi*x_hi per term
             peak = PEAK_FP16_MFMA_TFLOPS / products
-            shape = "16x16x32" if precision == "f16x2_s16" else "32x32x16"
-            arith = {"dtype": f"f32 operands as exact fp16 pairs, fp32 accumulate (v_mfma_f32_{shape}_f16 x3)",
-                     "kernel": "nerf_mlp_h3_kernel<rays>" if precision == "f16x2_s16" else "nerf_mlp_h2_kernel<rays>", "mfma_pipe": "f16", "mfma_pipe_peak": PEAK_FP16_MFMA_TFLOPS,
+            arith = {"dtype": "f32 operands as fp16 (hi, lo) pairs, fp32 accumulate (v_mfma_f32_32x32x16_f16 x3)",
+                     "kernel": "nerf_mlp_h2_kernel<rays>", "mfma_pipe": "f16", "mfma_pipe_peak": PEAK_FP16_MFMA_TFLOPS,
                      "mfma_products_per_term": products, "mfma_executed": achieved * products,
                      "vs_f32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS}
         else:

@@ -17,8 +17,15 @@
  *     enqueue work and return; they do not synchronise. Outputs are complete when the
  *     stream reaches the point after the call (the reference is synchronous only
  *     because eager PyTorch on one stream is).
- *   - One context per GPU. A context owns the packed weights and a workspace that
- *     grows on demand; it is not thread-safe, use one per host thread.
+ *   - One context per GPU. A context owns the packed weights and ONE scratch workspace (grown on
+ *     demand) that nerf_render_rays / nerf_render_frame / nerf_render_shard / nerf_train_step /
+ *     nerf_image_metrics all reuse. Those calls may come from several streams or host threads:
+ *     the library orders them itself (a mutex around the enqueue; a call on another stream than
+ *     the previous one first waits, on the device, for an event recorded after the previous
+ *     call), so they never overlap on the scratch - and therefore never overlap each other; for
+ *     concurrent renders on one GPU create one context per stream. Weight loading
+ *     (nerf_load_weights, nerf_set_adam_state) is not ordered against rendering on other
+ *     streams: finish it (or synchronise) first.
  *   - No CPU fallback exists: without a gfx950 device nerf_ctx_create fails.
  */
 #ifndef NERF_MI355X_H
@@ -71,19 +78,28 @@ void nerf_ctx_destroy(nerf_ctx* ctx);
  * activations between layers and everything outside the MLP are fp32 in both modes (the reference sets
  * torch.float32, nerf.ipynb:76); the modes differ in how the 256-wide contractions are evaluated:
  *   NERF_PRECISION_F32    v_mfma_f32_32x32x2_f32: an fp32 fmaf chain (24-bit operands).
- *   NERF_PRECISION_F16X2  every operand carried as two round-to-nearest fp16 numbers hi + lo (|v - hi - lo| <=
- *                         2^-24 |v|, what fp32 keeps), scaled per layer (weights) and per point (activations) by
- *                         powers of two so nothing leaves the fp16 range; three v_mfma_f32_32x32x16_f16
- *                         products per term (lo*lo is below fp32 resolution), fp32 accumulation.
- * A context starts in NERF_PRECISION_F16X2 (2.9x the frame rate, errors against an fp64 evaluation of the
- * network equal or smaller than the fp32 chain's: tests/test_hip_parity.py::test_mlp_precisions_vs_fp64).
+ *   NERF_PRECISION_F16X2  every operand v carried as two fp16 numbers, hi = rn16(v), lo = rn16(v - hi), scaled per
+ *                         layer (weights) and per point (activations) by powers of two so that nothing leaves the
+ *                         fp16 range; three v_mfma_f32_32x32x16_f16 products per term (W_lo x_hi + W_hi x_lo +
+ *                         W_hi x_hi, each exact in the fp32 accumulator), fp32 accumulation. What is proven:
+ *                         |v - hi - lo| <= 2^-23 |v| (the remainder v - hi has up to 12 significant bits, lo keeps
+ *                         11: up to one fp32 ulp is lost, none when the remainder fits) and the dropped W_lo x_lo is
+ *                         <= 2^-22 |W x| per product. That is a per-product bound about 4x the fp32 rounding unit;
+ *                         what is MEASURED is that through the whole network the error against an fp64 evaluation
+ *                         is equal or smaller than the fp32 MFMA chain's (rms <= 1.25x, max <= 2x, asserted by
+ *                         tests/test_hip_parity.py::test_mlp_precisions_vs_fp64 incl. adversarial scalings), because
+ *                         these errors are unbiased and far below the accumulated rounding of a 256-term fp32 sum.
+ *                         Limits, also tested: a weight more than 2^12 below the largest of its LAYER, or an
+ *                         activation more than 2^12 below the largest of its POINT, has a low half in the fp16
+ *                         subnormal range (absolute resolution 2^-24 of the scaled unit) and keeps fewer than 24
+ *                         bits; harmless when the large values feed the same outputs, a real loss when they do
+ *                         not (a row of tiny weights next to a row of huge ones; a huge activation that the next
+ *                         layer ignores). nerf_precision_status counts the loose-bound case; for such networks use
+ *                         NERF_PRECISION_F32.
+ * A context starts in NERF_PRECISION_F16X2 (about 3x the frame rate of the fp32 chain).
  * Takes effect for the following calls on this context; weights loaded earlier stay valid. */
 #define NERF_PRECISION_F32 0
 #define NERF_PRECISION_F16X2 1
-/* The same fp16-pair arithmetic on the other shape of the half-precision matrix pipe (v_mfma_f32_16x16x32_f16, two
- * 16-point column groups per wavefront; csrc/mlp_kernel_h3.hip): same accuracy, same frame rate on MI355X today
- * (DESIGN.md section 3.1); kept selectable because the clock the chip holds under this load depends on the shape. */
-#define NERF_PRECISION_F16X2_S16 2
 int nerf_set_precision(nerf_ctx* ctx, int precision);
 int nerf_get_precision(nerf_ctx* ctx);
 /* NERF_PRECISION_F16X2 chooses a layer's per-point output scale from an a-priori bound (largest row sum of |W| x

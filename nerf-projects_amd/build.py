@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnerf_mi355x.so")
-SOURCES = ["api.cpp", "train_api.cpp", "pack_weights.cpp", "mlp_kernel.hip", "mlp_kernel_h2.hip", "mlp_kernel_h3.hip", "ray_kernels.hip",
+SOURCES = ["api.cpp", "train_api.cpp", "pack_weights.cpp", "mlp_kernel.hip", "mlp_kernel_h2.hip", "ray_kernels.hip",
            "train_kernels.hip"]
 HEADERS = [os.path.join(CSRC, "nerf_internal.h"), os.path.join(CSRC, "ctx_internal.h"),
            os.path.join(CSRC, "mlp_inputs.h"), os.path.join(CSRC, "mlp_pair_common.h"),
@@ -29,7 +29,7 @@ FLAGS = [
 # v_accvgpr_read per element (578 -> 163 in the fp32 MLP kernel, +1.1 % frame rate, measured A/B).
 # The fp16-pair kernel holds 128 accumulators + 176 operand registers and needs the AGPR half for the former.
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
-EXTRA = {"mlp_kernel_h2.hip": [], "mlp_kernel_h3.hip": []}
+EXTRA = {"mlp_kernel_h2.hip": []}
 
 
 def hipcc():

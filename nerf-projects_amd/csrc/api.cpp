@@ -32,8 +32,6 @@ namespace {
 int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net, int mode, hipStream_t s) {
     a.stream = net.d_stream;
     a.stream_h2 = net.d_stream_h2;
-    a.stream_h3 = net.d_stream_h3;
-    a.bias3 = net.d_bias3;
     a.descale = net.d_descale;
     a.gain = net.d_gain;
     a.loose = c->d_loose;
@@ -67,8 +65,6 @@ int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net, int mode, hipStream
 #endif
     if (c->precision == NERF_PRECISION_F16X2)
         HIP_TRY(launch_mlp_h2(a, mode, s));
-    else if (c->precision == NERF_PRECISION_F16X2_S16)
-        HIP_TRY(launch_mlp_h3(a, mode, s));
     else
         HIP_TRY(launch_mlp(a, mode, s));
 #ifdef NERF_STAMPS
@@ -112,8 +108,7 @@ namespace {
 void free_net(PackedNet& n) {
     for (void* p : {(void*)n.d_stream, (void*)n.d_bias, (void*)n.d_params, (void*)n.train.d_grad, (void*)n.train.d_m,
                     (void*)n.train.d_v, (void*)n.train.d_wt, (void*)n.train.d_stream_table,
-                    (void*)n.train.d_bias_table, (void*)n.train.d_stream_table3, (void*)n.train.d_bias_table3,
-                    (void*)n.d_stream3, (void*)n.d_stream_h3, (void*)n.d_bias3, (void*)n.d_stream_h2, (void*)n.d_descale, (void*)n.d_chunk_layer,
+                    (void*)n.train.d_bias_table, (void*)n.d_stream_h2, (void*)n.d_descale, (void*)n.d_chunk_layer,
                     (void*)n.d_chunk_max, (void*)n.d_gain})
         if (p) (void)hipFree(p);
     n = PackedNet{};
@@ -228,6 +223,7 @@ void nerf_ctx_destroy(nerf_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->frame_rays) (void)hipFree(c->frame_rays);
     if (c->d_loose) (void)hipFree(c->d_loose);
+    if (c->scratch_done) (void)hipEventDestroy(c->scratch_done);
     for (auto& p : c->events) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -237,7 +233,7 @@ void nerf_ctx_destroy(nerf_ctx* c) {
 }
 
 int nerf_set_precision(nerf_ctx* c, int precision) {
-    if (!c || (precision != NERF_PRECISION_F32 && precision != NERF_PRECISION_F16X2 && precision != NERF_PRECISION_F16X2_S16)) {
+    if (!c || (precision != NERF_PRECISION_F32 && precision != NERF_PRECISION_F16X2)) {
         set_error("nerf_set_precision: invalid argument");
         return NERF_E_INVALID;
     }
@@ -304,23 +300,6 @@ int nerf_load_weights(nerf_ctx* c, int slot, const nerf_arch* arch, const float*
         for (size_t i = 0; i < net.bias_table.size(); ++i) net.bias_table[i] = (int)tb[i] - 1;
         free(ts);
         free(tb);
-        // the same for the 16x16x32 layout (mlp_kernel_h3.hip)
-        ts = tb = nullptr;
-        rc = pack_weights(*arch, fake_ptrs.data(), n_tensors, &ts, &tnc, &tb, &tnb, &tm, &toc, 1);
-        if (rc != NERF_OK || tnc != nc || tnb != nbt) {
-            free(hs);
-            free(hb);
-            free(ts);
-            free(tb);
-            if (rc == NERF_OK) set_error("internal: the two weight layouts disagree in size");
-            return rc != NERF_OK ? rc : NERF_E_INVALID;
-        }
-        net.stream_table3.resize((size_t)tnc * kChunkFloats);
-        net.bias_table3.resize((size_t)tnb * kBiasTileFloats);
-        for (size_t i = 0; i < net.stream_table3.size(); ++i) net.stream_table3[i] = (int)ts[i] - 1;
-        for (size_t i = 0; i < net.bias_table3.size(); ++i) net.bias_table3[i] = (int)tb[i] - 1;
-        free(ts);
-        free(tb);
         net.n_params = total;
     }
     if (e == hipSuccess) e = hipMalloc((void**)&net.d_params, net.n_params * sizeof(float));
@@ -347,25 +326,6 @@ int nerf_load_weights(nerf_ctx* c, int slot, const nerf_arch* arch, const float*
     if (e == hipSuccess)
         e = launch_convert_stream_h2(net.d_stream, net.d_chunk_layer, nc, net.d_chunk_max, net.d_stream_h2,
                                      net.d_descale, nullptr);
-    // the 16x16x32 kernel's copies: gathered from the master parameters through the layout-1 tables, then converted
-    // (same chunks, same layers, so the same per-layer scales land in d_descale again)
-    int *d_t3 = nullptr, *d_b3 = nullptr;
-    if (e == hipSuccess) e = hipMalloc((void**)&net.d_stream3, (size_t)nc * kChunkBytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&net.d_stream_h3, (size_t)nc * kChunkBytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&net.d_bias3, (size_t)nbt * kBiasTileFloats * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_t3, net.stream_table3.size() * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_b3, net.bias_table3.size() * sizeof(int));
-    if (e == hipSuccess)
-        e = hipMemcpy(d_t3, net.stream_table3.data(), net.stream_table3.size() * sizeof(int), hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = hipMemcpy(d_b3, net.bias_table3.data(), net.bias_table3.size() * sizeof(int), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = launch_gather(net.d_params, d_t3, (int64_t)net.stream_table3.size(), net.d_stream3, nullptr);
-    if (e == hipSuccess) e = launch_gather(net.d_params, d_b3, (int64_t)net.bias_table3.size(), net.d_bias3, nullptr);
-    if (e == hipSuccess)
-        e = launch_convert_stream_h2(net.d_stream3, net.d_chunk_layer, nc, net.d_chunk_max, net.d_stream_h3,
-                                     net.d_descale, nullptr);
-    net.train.d_stream_table3 = d_t3;   // kept for the refresh after optimiser steps (freed with the net)
-    net.train.d_bias_table3 = d_b3;
     if (e == hipSuccess) e = hipMalloc((void**)&net.d_gain, 2 * (kMaxDepth + 2) * sizeof(float));
     if (e == hipSuccess) e = launch_layer_gains(net.d_params, gain_refs(*arch, net.linears), net.d_gain, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -487,7 +447,7 @@ int nerf_resample(nerf_ctx* c, const float* z_vals, const float* weights, const 
     return NERF_OK;
 }
 
-int nerf_render_rays(nerf_ctx* c, const nerf_render_args* r) {
+static int render_rays_locked(nerf_ctx* c, const nerf_render_args* r) {
     if (!c || !r || (!r->rays && r->n_rays != 0) || r->n_rays < 0) {
         set_error("nerf_render_rays: NULL argument");
         return NERF_E_INVALID;
@@ -592,6 +552,17 @@ int nerf_render_rays(nerf_ctx* c, const nerf_render_args* r) {
     return NERF_OK;
 }
 
+int nerf_render_rays(nerf_ctx* c, const nerf_render_args* r) {
+    if (!c || !r) {
+        set_error("nerf_render_rays: NULL argument");
+        return NERF_E_INVALID;
+    }
+    DeviceGuard g(c->device);
+    ScratchScope scope(c, (hipStream_t)r->stream);
+    HIP_TRY(scope.status);
+    return render_rays_locked(c, r);
+}
+
 int nerf_generate_rays(nerf_ctx* c, const nerf_camera* cam, int64_t first_pixel, int64_t n_pixels, float* rays,
                        void* stream) {
     if (!c || !cam || first_pixel < 0 || n_pixels < 0) {
@@ -629,6 +600,8 @@ int nerf_render_frame(nerf_ctx* c, const nerf_frame_args* f) {
     const int64_t per = chunk < f->n_pixels ? chunk : f->n_pixels;
     DeviceGuard g(c->device);
     hipStream_t s = (hipStream_t)f->stream;
+    ScratchScope scope(c, s);
+    HIP_TRY(scope.status);
     if ((size_t)per * ld > c->frame_rays_floats) {
         if (c->frame_rays) {
             HIP_TRY(hipDeviceSynchronize());
@@ -662,7 +635,7 @@ int nerf_render_frame(nerf_ctx* c, const nerf_frame_args* f) {
         r.acc0 = f->acc0 ? f->acc0 + off : nullptr;
         r.z_std = f->z_std ? f->z_std + off : nullptr;
         r.stream = f->stream;
-        const int rc = nerf_render_rays(c, &r);
+        const int rc = render_rays_locked(c, &r);
         if (rc != NERF_OK) return rc;
     }
     return NERF_OK;
@@ -703,6 +676,8 @@ int nerf_image_metrics(nerf_ctx* c, const float* img1, const float* img2, int H,
         return NERF_E_INVALID;
     }
     DeviceGuard g(c->device);
+    ScratchScope scope(c, (hipStream_t)stream);
+    HIP_TRY(scope.status);
     const size_t total = (size_t)H * W * 3;
     const size_t blocks = (total + 255) / 256;
     int rc = ensure_workspace(c, arena_bytes({5 * total, 4 * blocks + 16}));

@@ -2,6 +2,7 @@
 #pragma once
 #include <cstddef>
 #include <initializer_list>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -25,6 +26,14 @@ struct nerf_ctx {
     size_t ws_bytes = 0;
     float* frame_rays = nullptr;   // ray record of the chunk being rendered by nerf_render_frame
     size_t frame_rays_floats = 0;
+    // The scratch above is shared by every call on this context (nerf_render_rays, nerf_render_frame, nerf_train_step,
+    // nerf_image_metrics). Calls are asynchronous, so two calls may only reuse it in stream order: ScratchScope
+    // (below) serialises host threads with `scratch_mutex` and, when a call arrives on another stream than the one
+    // before it, makes that stream wait for `scratch_done`, recorded when the previous call finished enqueueing.
+    std::mutex scratch_mutex;
+    hipEvent_t scratch_done = nullptr;
+    hipStream_t scratch_stream = nullptr;
+    bool scratch_used = false;
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per MLP launch
     std::vector<hipEvent_t> pool;
@@ -45,6 +54,30 @@ struct DeviceGuard {
     ~DeviceGuard() {
         if (prev >= 0) (void)hipSetDevice(prev);
     }
+};
+
+// Ownership of the context's scratch for the duration of one API call (see nerf_ctx::scratch_mutex). Recursive use
+// (nerf_render_frame -> nerf_render_rays) is handled by the caller passing its own scope down: only the outermost call
+// creates one.
+struct ScratchScope {
+    nerf_ctx* c;
+    hipStream_t s;
+    hipError_t status = hipSuccess;
+    ScratchScope(nerf_ctx* ctx, hipStream_t stream) : c(ctx), s(stream) {
+        c->scratch_mutex.lock();
+        if (!c->scratch_done) status = hipEventCreateWithFlags(&c->scratch_done, hipEventDisableTiming);
+        if (status == hipSuccess && c->scratch_used && c->scratch_stream != s)
+            status = hipStreamWaitEvent(s, c->scratch_done, 0);
+    }
+    ~ScratchScope() {
+        if (c->scratch_done && hipEventRecord(c->scratch_done, s) == hipSuccess) {
+            c->scratch_stream = s;
+            c->scratch_used = true;
+        }
+        c->scratch_mutex.unlock();
+    }
+    ScratchScope(const ScratchScope&) = delete;
+    ScratchScope& operator=(const ScratchScope&) = delete;
 };
 
 inline int ensure_workspace(nerf_ctx* c, size_t bytes) {

@@ -7,11 +7,13 @@
 // v_mfma_f32_32x32x2_f32:
 //
 //   * every fp32 operand v is carried as two fp16 numbers, v ~= hi + lo with hi = rn16(v) and
-//     lo = rn16(v - hi): |v - hi - lo| <= 2^-24 |v|, what fp32 itself keeps. A product W*x is the three
-//     v_mfma_f32_32x32x16_f16 terms W_lo*x_hi + W_hi*x_lo + W_hi*x_hi (fp16 x fp16 is exact in the fp32
-//     accumulator; the dropped W_lo*x_lo is below 2^-24 relative). Against an fp64 evaluation of the 8x256 network
-//     the result is as close as the fp32 MFMA chain's, or closer (tests: test_mlp_precisions_vs_fp64;
-//     profiles/microbench/mfma_bf16_split.hip has the single-layer numbers and the schemes that were ruled out).
+//     lo = rn16(v - hi): |v - hi - lo| <= 2^-23 |v| (the remainder has up to 12 significant bits, lo keeps 11: at
+//     most one fp32 ulp is lost). A product W*x is the three v_mfma_f32_32x32x16_f16 terms
+//     W_lo*x_hi + W_hi*x_lo + W_hi*x_hi (fp16 x fp16 is exact in the fp32 accumulator); the dropped W_lo*x_lo is
+//     <= 2^-22 |W x| per product. Per product that is ~4x the fp32 rounding unit; measured through the 8x256 network
+//     against an fp64 evaluation the result is as close as the fp32 MFMA chain's, or closer (the errors are unbiased
+//     and small next to the accumulated rounding of a 256-term fp32 sum): tests test_mlp_precisions_vs_fp64;
+//     profiles/microbench/mfma_bf16_split.hip has the single-layer numbers and the schemes that were ruled out.
 //   * fp16 has 5 exponent bits, so both operands are kept in range by exact power-of-two scalings:
 //     each layer's weights by one factor chosen from the layer's largest |w| (convert kernel below; the
 //     inverse factor travels in `descale`), each POINT's activation vector by its own factor, chosen
@@ -117,26 +119,14 @@ struct Pending {
     float m;       // running max |y|
 };
 
-// NERF_V2_ACCREAD: the pending layer's sums stay in the accumulator registers they were produced in and are fetched
-// one pair per step (v_accvgpr_read in the MFMA shadow) instead of 128 at the layer boundary
-__device__ __forceinline__ float acc_get(const float& a) {
-#ifdef NERF_V2_ACCREAD
-    float v;
-    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
-    return v;
-#else
-    return a;
-#endif
-}
-
 template <int P>
 __device__ __forceinline__ void convert_pair(XT& dst, const f32x16& src, Pending& pd, const f32x2& b) {
 #ifdef NERF_ABLATE_CONV
     if (P == 0) dst.hi[0][0] = __float_as_uint(src[0] + b[0]);
     return;
 #endif
-    const float y0 = fmaxf(fmaf(acc_get(src[2 * P]), pd.c, b[0]), pd.floor);
-    const float y1 = fmaxf(fmaf(acc_get(src[2 * P + 1]), pd.c, b[1]), pd.floor);
+    const float y0 = fmaxf(fmaf(src[2 * P], pd.c, b[0]), pd.floor);
+    const float y1 = fmaxf(fmaf(src[2 * P + 1], pd.c, b[1]), pd.floor);
     pd.m = fmaxf(fmaxf(pd.m, fabsf(y0)), fabsf(y1));
     const float a0 = y0 * pd.sc, a1 = y1 * pd.sc;
     const unsigned hi = __builtin_bit_cast(unsigned, round_pair(a0, a1));
@@ -170,8 +160,8 @@ __device__ __forceinline__ void conv_slice0(ConvTmp& t, const f32x16& src, const
     t.y0 = src[2 * P] + b[0]; t.y1 = 0.0f;
     return;
 #endif
-    t.y0 = fmaxf(fmaf(acc_get(src[2 * P]), pd.c, b[0]), pd.floor);
-    t.y1 = fmaxf(fmaf(acc_get(src[2 * P + 1]), pd.c, b[1]), pd.floor);
+    t.y0 = fmaxf(fmaf(src[2 * P], pd.c, b[0]), pd.floor);
+    t.y1 = fmaxf(fmaf(src[2 * P + 1], pd.c, b[1]), pd.floor);
 }
 __device__ __forceinline__ void conv_slice1(ConvTmp& t, Pending& pd) {
 #ifdef NERF_ABLATE_CONV

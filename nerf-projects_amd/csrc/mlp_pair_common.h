@@ -1,5 +1,4 @@
-// Shared machinery of the two fp16-pair MLP kernels (mlp_kernel_h2.hip: v_mfma_f32_32x32x16_f16, mlp_kernel_h3.hip:
-// v_mfma_f32_16x16x32_f16): the LDS-DMA weight ring, the hand-placed step with its counted LDS waits, the power-of-two
+// Machinery of the fp16-pair MLP kernel (mlp_kernel_h2.hip, v_mfma_f32_32x32x16_f16): the LDS-DMA weight ring, the hand-placed step with its counted LDS waits, the power-of-two
 // scaling and the exact (hi, lo) fp16 split, LDS reads outside hipcc's LDS-DMA guard.
 #pragma once
 #include "mlp_inputs.h"
@@ -11,8 +10,7 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// one 32-feature activation tile as MFMA B operands: two u32x4 of packed halves each for hi and lo (32x32x16 kernel:
-// [k-slice], 16x16x32 kernel: [point group])
+// one 32-feature activation tile as MFMA B operands: two u32x4 of packed halves each for hi and lo ([k-slice])
 struct XT {
     u32x4 hi[2], lo[2];
 };
@@ -223,8 +221,8 @@ __device__ __forceinline__ float tile_absmax(const f32x16& v, float m) {
     return m;
 }
 
-// v_cvt_pk_f16_f32: both halves rounded to nearest even. hi = rn16(v) leaves |v - hi| <= 2^-12 |v| (exact in fp32),
-// lo = rn16(v - hi) leaves 2^-24 |v|: the pair carries as many bits as the fp32 it came from.
+// v_cvt_pk_f16_f32: both halves rounded to nearest even. hi = rn16(v) leaves |v - hi| <= 2^-11 |v| (exact in fp32, up
+// to 12 significant bits), lo = rn16(v - hi) keeps 11 of them: |v - hi - lo| <= 2^-23 |v|, at most one fp32 ulp.
 __device__ __forceinline__ h16x2 round_pair(float a, float b) {
     const f32x2 v = {a, b};
     return __builtin_convertvector(v, h16x2);

@@ -43,25 +43,6 @@ __host__ __device__ constexpr int pe_col_dir(int t, int h) {
          : t == 12 ? (h ? 2 : 0) : (t == 13 ? (h ? -1 : 1) : -1);
 }
 
-// ---- slot maps of the 16x16x32 layout (mlp_kernel_h3.hip) ---------------------------------------------------------
-// There a lane is (column c = lane & 15, k-group g = lane >> 4) and serves two points (c and 16 + c of its wave); the
-// B operand of a 32-deep k-tile holds, for lane (c, g), positions j = 0..7 = k index 8g + j.
-// Hidden activations: position (kt, g, j) is feature 32 kt + 16 (j >> 2) + 4 g + (j & 3) - the accumulator registers
-// of the two 16-row output tiles 2 kt, 2 kt + 1 in the order the lane holds them.
-__host__ __device__ constexpr int hidden_col3(int kt, int g, int j) { return 32 * kt + 16 * (j >> 2) + 4 * g + (j & 3); }
-// gamma(xyz): pair q = (4 t + g) * 4 + (j >> 1) of k-tile t; q < 30 is (frequency q / 3, component q % 3) with the sine
-// in the even and the cosine in the odd position, so a lane evaluates one sincosf per pair and nothing crosses lanes;
-// q = 30 holds (x, y), q = 31 (z, padding).
-__host__ __device__ constexpr int pe3_col_xyz(int t, int g, int j) {
-    const int q = (4 * t + g) * 4 + (j >> 1);
-    return q < 30 ? 3 + 6 * (q / 3) + 3 * (j & 1) + (q % 3) : q == 30 ? (j & 1) : ((j & 1) ? -1 : 2);
-}
-// gamma(dir): one k-tile, pair q = 4 g + (j >> 1); q < 12 sin/cos, q = 12 (x, y), q = 13 (z, padding), then padding
-__host__ __device__ constexpr int pe3_col_dir(int g, int j) {
-    const int q = 4 * g + (j >> 1);
-    return q < 12 ? 3 + 6 * (q / 3) + 3 * (j & 1) + (q % 3) : q == 12 ? (j & 1) : (q == 13 && !(j & 1)) ? 2 : -1;
-}
-
 // one nn.Linear inside the flat parameter buffer (state_dict order: weight [out,in] then bias [out])
 struct LinearDesc {
     int out = 0, in = 0;
@@ -77,8 +58,6 @@ struct TrainState {
     float* d_wt = nullptr;       // every weight transposed ([in,out]) at the same w_off: B operand of the forward GEMMs
     int* d_stream_table = nullptr;   // fused-stream element -> index into params (or -1)
     int* d_bias_table = nullptr;
-    int* d_stream_table3 = nullptr;  // the same for the 16x16x32 layout
-    int* d_bias_table3 = nullptr;
     bool grads_valid = false;
 };
 
@@ -89,7 +68,6 @@ struct PackedNet {
     size_t n_params = 0;
     std::vector<LinearDesc> linears;   // pts_linears[0..D-1], views, then feature, alpha, rgb | output
     std::vector<int> stream_table, bias_table;
-    std::vector<int> stream_table3, bias_table3;   // 16x16x32 layout (mlp_kernel_h3.hip)
     TrainState train;
     float* d_stream = nullptr;   // n_chunks * kChunkFloats
     float* d_bias = nullptr;     // n_bias_tiles * kBiasTileFloats
@@ -99,11 +77,6 @@ struct PackedNet {
     float* d_descale = nullptr;
     int* d_chunk_layer = nullptr;
     float* d_chunk_max = nullptr;
-    // the same network packed for the 16x16x32 fp16-pair kernel (mlp_kernel_h3.hip): fp32 fragments in that kernel's
-    // order (source of the conversion and of the training refresh), their (hi, lo) twin and the bias block in its order
-    float* d_stream3 = nullptr;
-    uint32_t* d_stream_h3 = nullptr;
-    float* d_bias3 = nullptr;
     float* d_gain = nullptr;     // per layer [max row sum of |W|, max |b|]: bounds a layer's outputs from its inputs
     int n_chunks = 0;
     int n_bias_tiles = 0;
@@ -116,8 +89,6 @@ enum MlpInputMode { kInputEmbedded = 0, kInputPoints = 1, kInputRays = 2 };
 struct MlpLaunch {
     const float* stream;
     const uint32_t* stream_h2;   // NERF_PRECISION_F16X2 only
-    const uint32_t* stream_h3;   // NERF_PRECISION_F16X2, 16x16x32 kernel
-    const float* bias3;
     const float* descale;
     const float* gain;
     unsigned* loose;             // counter of (wave, layer) events where the a-priori output bound was >= 2^12 x too wide
@@ -147,10 +118,9 @@ struct MlpLaunch {
 };
 
 // host-side packer (pack_weights.cpp)
-// layout 0: 32x32 fragments (mlp_kernel.hip, mlp_kernel_h2.hip); layout 1: 16x16x32 fragments (mlp_kernel_h3.hip)
 int pack_weights(const nerf_arch& arch, const float* const* tensors, int n_tensors,
                  float** stream_out, int* n_chunks, float** bias_out, int* n_bias_tiles,
-                 uint32_t* skip_in_mask, int* out_ch, int layout = 0);
+                 uint32_t* skip_in_mask, int* out_ch);
 
 // scale group ("layer") of every chunk of the stream, in stream order
 std::vector<int> chunk_layers(const nerf_arch& arch, uint32_t skip_in_mask);
@@ -158,7 +128,6 @@ std::vector<int> chunk_layers(const nerf_arch& arch, uint32_t skip_in_mask);
 // kernel launchers (mlp_kernel.hip, mlp_kernel_h2.hip, ray_kernels.hip)
 hipError_t launch_mlp(const MlpLaunch& a, int mode, hipStream_t s);
 hipError_t launch_mlp_h2(const MlpLaunch& a, int mode, hipStream_t s);
-hipError_t launch_mlp_h3(const MlpLaunch& a, int mode, hipStream_t s);
 // the Linear whose outputs are re-quantised after layer l (trunk 0..D-1, then feature_linear), for launch_layer_gains
 struct GainRefs {
     int n;

@@ -41,23 +41,15 @@ struct Linear {
     float bias(int r) const { return r < out ? b[r] : 0.0f; }
 };
 
-// group g of a chunk: 64 lanes x 4 consecutive k-steps.
-// Layout 0: lane = (row lane & 31, half h = lane >> 5), group t4 of a unit holds k-steps 4 t4 .. 4 t4 + 3 -> col(t, h).
-// Layout 1 (16x16x32): a unit's groups are [tile T = t4 >> 1][jj = t4 & 1]: lane = (row lane & 15, k-group g = lane >> 4)
-// of the 16-row tile 2 ot + T, positions j = 4 jj .. 4 jj + 3 -> col(j, g).
-thread_local int g_layout = 0;   // set by pack_weights for the duration of one call
+// group g of a chunk: 64 lanes x 4 consecutive k-steps: lane = (row lane & 31, half h = lane >> 5), group t4 of a unit
+// holds k-steps 4 t4 .. 4 t4 + 3 -> col(t, h).
 
 template <class ColFn>
 void fill_group(float* chunk, int g, const Linear& L, int ot, int t4, ColFn col) {
     float* dst = chunk + (size_t)g * kGroupFloats;
     for (int lane = 0; lane < 64; ++lane) {
-        if (g_layout == 0) {
-            const int row = 32 * ot + (lane & 31), h = lane >> 5;
-            for (int j = 0; j < 4; ++j) dst[lane * 4 + j] = L.at(row, col(4 * t4 + j, h));
-        } else {
-            const int row = 32 * ot + 16 * (t4 >> 1) + (lane & 15), kg = lane >> 4;
-            for (int j = 0; j < 4; ++j) dst[lane * 4 + j] = L.at(row, col(4 * (t4 & 1) + j, kg));
-        }
+        const int row = 32 * ot + (lane & 31), h = lane >> 5;
+        for (int j = 0; j < 4; ++j) dst[lane * 4 + j] = L.at(row, col(4 * t4 + j, h));
     }
 }
 
@@ -69,39 +61,24 @@ void chunk_ktile(Stream& s, const Linear& L, int n_ot, ColFn col) {
         for (int t4 = 0; t4 < 4; ++t4) fill_group(c, ot * 4 + t4, L, ot, t4, col);
 }
 
-// feature held by accumulator register r of 32-row tile `tile` in lane class hg (layout 0: half-wave h; layout 1:
-// k-group g, registers ordered [point group][T][i], the point group not mattering here)
-inline int acc_feature(int tile, int r, int hg) {
-    return g_layout == 0 ? hidden_col(tile, r, hg) : 32 * tile + 16 * ((r >> 2) & 1) + 4 * hg + (r & 3);
-}
+// feature held by accumulator register r of 32-row tile `tile` in half-wave h
+inline int acc_feature(int tile, int r, int h) { return hidden_col(tile, r, h); }
 
 void bias_tiles(std::vector<float>& out, const Linear& L, int n_ot) {
-    for (int ot = 0; ot < n_ot; ++ot) {
-        if (g_layout == 0) {
-            for (int h = 0; h < 2; ++h)
-                for (int r = 0; r < 16; ++r) out.push_back(L.bias(acc_feature(ot, r, h)));
-        } else {
-            for (int kg = 0; kg < 4; ++kg)
-                for (int r = 0; r < 8; ++r) out.push_back(L.bias(acc_feature(ot, r, kg)));   // [g][T][i]
-        }
-    }
+    for (int ot = 0; ot < n_ot; ++ot)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) out.push_back(L.bias(acc_feature(ot, r, h)));
 }
 
 // row `row` of a weight matrix over its first 32*n_kt input columns, in accumulator-register order
 void row_tiles(std::vector<float>& out, const Linear& L, int row, int n_kt) {
-    for (int kt = 0; kt < n_kt; ++kt) {
-        if (g_layout == 0) {
-            for (int h = 0; h < 2; ++h)
-                for (int r = 0; r < 16; ++r) out.push_back(L.at(row, acc_feature(kt, r, h)));
-        } else {
-            for (int kg = 0; kg < 4; ++kg)
-                for (int r = 0; r < 8; ++r) out.push_back(L.at(row, acc_feature(kt, r, kg)));
-        }
-    }
+    for (int kt = 0; kt < n_kt; ++kt)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) out.push_back(L.at(row, acc_feature(kt, r, h)));
 }
 
-// input column of hidden k-tile kt at (t, h) / (j, g)
-inline int hid_col(int kt, int a, int b) { return g_layout == 0 ? hidden_col(kt, a, b) : hidden_col3(kt, b, a); }
+// input column of hidden k-tile kt at (t, h)
+inline int hid_col(int kt, int t, int h) { return hidden_col(kt, t, h); }
 
 }  // namespace
 
@@ -125,8 +102,7 @@ std::vector<int> chunk_layers(const nerf_arch& a, uint32_t mask) {
 
 int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors, float** stream_out,
                  int* n_chunks, float** bias_out, int* n_bias_tiles, uint32_t* skip_in_mask,
-                 int* out_ch, int layout) {
-    g_layout = layout;
+                 int* out_ch) {
     if (a.W != kWidth) {
         set_error("unsupported netwidth W=%d: this build specialises the MLP kernel for W=%d", a.W, kWidth);
         return NERF_E_INVALID;
@@ -186,7 +162,7 @@ int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors,
     auto xyz_col = [&](int tile) {
         const int nx = a.input_ch;
         return [tile, nx](int t, int h) {
-            const int c = g_layout == 0 ? pe_col_xyz(16 * tile + t, h) : pe3_col_xyz(tile, h, t);
+            const int c = pe_col_xyz(16 * tile + t, h);
             return (c >= 0 && c < nx) ? c : -1;
         };
     };
@@ -249,7 +225,7 @@ int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors,
             const int off = a.W;
             const int nv = a.input_ch_views;
             chunk_ktile(st, views, 4, [off, nv](int t, int h) {
-                const int c = g_layout == 0 ? pe_col_dir(t, h) : pe3_col_dir(h, t);
+                const int c = pe_col_dir(t, h);
                 return (c >= 0 && c < nv) ? off + c : -1;
             });
         }

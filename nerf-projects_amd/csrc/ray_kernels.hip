@@ -299,9 +299,23 @@ hipError_t launch_sample_pdf(const float* bins, const float* weights, int w_ld, 
                              float* z_std, hipStream_t s) {
     if (N <= 0) return hipSuccess;
     if (N > 0x7fffffffLL) return hipErrorInvalidValue;
-    int n_sort = 2;
-    while (n_sort < M + 1 + n_samples) n_sort <<= 1;
+    int n_sort = 0;                       // the merge buffer exists only when a merged output is asked for
+    if (z_merged) {
+        n_sort = 2;
+        while (n_sort < M + 1 + n_samples) n_sort <<= 1;
+    }
     const size_t lds = sizeof(float) * (size_t)(2 * M + n_sort);
+    // up to 2 x 4096 + 8192 floats = 64 KiB at the documented argument limits: above the 48 KiB a kernel gets by default
+    static size_t raised[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (lds > 48 * 1024 && lds > raised[dev]) {
+        e = hipFuncSetAttribute((const void*)sample_pdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised[dev] = lds;
+    }
     hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)N), dim3(64), lds, s, bins, weights, w_ld, w_off, z_coarse,
                        u, M, n_samples, n_sort, samples, z_merged, z_std);
     return hipGetLastError();

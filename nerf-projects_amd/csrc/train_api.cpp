@@ -42,10 +42,6 @@ int refresh_derived(PackedNet& net, hipStream_t s) {
     HIP_TRY(launch_gather(net.d_params, net.train.d_bias_table, (int64_t)net.bias_table.size(), net.d_bias, s));
     HIP_TRY(launch_convert_stream_h2(net.d_stream, net.d_chunk_layer, net.n_chunks, net.d_chunk_max, net.d_stream_h2,
                                      net.d_descale, s));
-    HIP_TRY(launch_gather(net.d_params, net.train.d_stream_table3, (int64_t)net.stream_table3.size(), net.d_stream3, s));
-    HIP_TRY(launch_gather(net.d_params, net.train.d_bias_table3, (int64_t)net.bias_table3.size(), net.d_bias3, s));
-    HIP_TRY(launch_convert_stream_h2(net.d_stream3, net.d_chunk_layer, net.n_chunks, net.d_chunk_max, net.d_stream_h3,
-                                     net.d_descale, s));
     HIP_TRY(launch_layer_gains(net.d_params, gain_refs(net.arch, net.linears), net.d_gain, s));
     return NERF_OK;
 }
@@ -291,6 +287,8 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     }
     DeviceGuard guard(c->device);
     hipStream_t s = (hipStream_t)r->stream;
+    ScratchScope scope(c, s);
+    HIP_TRY(scope.status);
     int rc;
     for (PackedNet* n : {&nc, &nf}) {
         const bool fresh = !n->train.ready;

@@ -48,7 +48,7 @@ class Context:
         if default:
             self.set_precision(default)
 
-    PRECISIONS = {"f32": 0, "f16x2": 1, "f16x2_s16": 2}
+    PRECISIONS = {"f32": 0, "f16x2": 1}
 
     def set_precision(self, name):
         """Arithmetic of the fused MLP kernel: "f32" (fp32 MFMA) or "f16x2" (exact fp16-pair split, 3 MFMAs per term)."""
@@ -1013,11 +1013,17 @@ class Adam:
             keys = m.state_dict_keys()
             entries = [state.get(idx + j) for j in range(len(keys))]
             idx += len(keys)
-            if any(e is None for e in entries):
-                raise ValueError("optimizer state does not cover every parameter of the models")
-            m.load_adam_state([e['exp_avg'].detach().cpu().numpy() for e in entries],
-                              [e['exp_avg_sq'].detach().cpu().numpy() for e in entries])
-            steps = int(float(entries[0]['step']))
+            # torch.optim.Adam keeps state only for parameters that ever received a gradient: with use_viewdirs=False
+            # the reference's views_linears.0.* never do (nerf/nerf.py:43 registers them regardless), so its checkpoints
+            # have no entry for them. A missing entry is a parameter whose moments are still zero.
+            zeros = [np.zeros(m._expected_shape(k), np.float32) for k in keys]
+            m.load_adam_state([z if e is None else e['exp_avg'].detach().cpu().numpy() for e, z in zip(entries, zeros)],
+                              [z if e is None else e['exp_avg_sq'].detach().cpu().numpy() for e, z in zip(entries, zeros)])
+            present = [e for e in entries if e is not None]
+            if present:
+                steps = max(steps, int(float(present[0]['step'])))
+        if idx < len(state) or any(k >= idx for k in state):
+            raise ValueError(f"optimizer state has entries for {max(state) + 1} parameters, the models have {idx}")
         self.steps = steps
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Audit of the hand-counted LDS waits in the fused MLP kernels' generated code.
 
-The fp16-pair kernels (csrc/mlp_kernel_h2.hip, mlp_kernel_h3.hip) issue their LDS reads from inline asm and wait for
+The fp16-pair kernel (csrc/mlp_kernel_h2.hip) issues its LDS reads from inline asm and wait for
 them with hand-counted `s_waitcnt lgkmcnt(N)` statements, which pins the ORDER of the statements but not what hipcc
 does with the destination registers in between (cdna_hip_programming.md, "What hipcc does not do", item 1). This script
 walks the assembly of a kernel (hipcc -save-temps output) in program order, keeps the queue of LDS operations in
