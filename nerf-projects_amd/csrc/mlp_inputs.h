@@ -66,11 +66,18 @@ __device__ __forceinline__ void encode_point(const float (&p)[3], const float (&
     }
 }
 
+// bit 0: a position input of the point is NaN or infinite, bit 1: a direction input is. F.relu propagates NaN
+// (nerf/nerf.py:72) and v_max_f32 does not, so the kernels restore the reference's result on such points at the end:
+// every output channel NaN for a bad position, the colour channels NaN for a bad direction (sigma comes from the trunk).
+constexpr unsigned kBadXyz = 1u, kBadDir = 2u;
+__device__ __forceinline__ bool nonfinite(float v) { return !(fabsf(v) <= 3.4028234663852886e38f); }
+
 // WANT_XYZ / WANT_DIR: which tiles the caller uses (the other is left untouched). dir_max: largest |component| of the
 // direction (an upper bound of |gamma(dir)| together with 1), or of the encoded direction columns in embedded mode.
+// bad: kBadXyz | kBadDir of this point's raw inputs (both halves of a point get the same value).
 template <int MODE, bool WANT_XYZ = true, bool WANT_DIR = true>
 __device__ __forceinline__ void load_inputs(const MlpLaunch& a, int64_t pt, int h, f32x16& x0, f32x16& x1,
-                                            f32x16& dd, float* dir_max = nullptr) {
+                                            f32x16& dd, float* dir_max = nullptr, unsigned* bad = nullptr) {
     if (MODE == kInputEmbedded) {
         const float* row = a.x + pt * a.x_ld;
         if constexpr (WANT_XYZ) {
@@ -92,6 +99,13 @@ __device__ __forceinline__ void load_inputs(const MlpLaunch& a, int64_t pt, int 
             }
         }
         if (dir_max) *dir_max = fmaxf(m, __shfl_xor(m, 32));
+        if (bad) {
+            bool bx = false, bd = false;
+            for (int c = 0; c < a.in_ch; ++c) bx |= nonfinite(row[c]);
+            if (a.use_viewdirs)
+                for (int c = 0; c < a.in_ch_views; ++c) bd |= nonfinite(row[a.in_ch + c]);
+            *bad = (bx ? kBadXyz : 0u) | (bd ? kBadDir : 0u);
+        }
         return;
     }
     float p[3], d[3] = {0.0f, 0.0f, 0.0f};
@@ -118,6 +132,9 @@ __device__ __forceinline__ void load_inputs(const MlpLaunch& a, int64_t pt, int 
         }
     }
     if (dir_max) *dir_max = fmaxf(fmaxf(fabsf(d[0]), fabsf(d[1])), fmaxf(fabsf(d[2]), 1.0f));
+    if (bad)
+        *bad = ((nonfinite(p[0]) || nonfinite(p[1]) || nonfinite(p[2])) ? kBadXyz : 0u) |
+               ((nonfinite(d[0]) || nonfinite(d[1]) || nonfinite(d[2])) ? kBadDir : 0u);
     encode_point<WANT_XYZ, WANT_DIR>(p, d, h, a.use_viewdirs != 0, x0, x1, dd);
 }
 

@@ -289,6 +289,11 @@ void nerf_mlp_kernel(const MlpLaunch a) {
     }
 
     const bool live = pt_raw < a.n_points;
+    unsigned bad;      // NaN / Inf inputs propagate as through F.relu (mlp_inputs.h, kBadXyz): raw inputs re-read here
+    {
+        f32x16 t0, t1, t2;
+        load_inputs<MODE, false, false>(a, pt, h, t0, t1, t2, nullptr, &bad);
+    }
     if (a.use_viewdirs) {
         // views_linears[0] on cat[feature, gamma(dir)] (nerf.py:93-98): 4 output tiles
         load_bias<4>(acc, bias_lds, 8 * a.D + 9, h);
@@ -304,6 +309,10 @@ void nerf_mlp_kernel(const MlpLaunch a) {
         if (live && h == 0) {
             // outputs = cat[rgb, alpha] (nerf.py:106)
             f32x4 o = {r0, r1, r2, sigma};
+            if (bad) {
+                const float qnan = __builtin_nanf("");
+                o = f32x4{qnan, qnan, qnan, (bad & kBadXyz) ? qnan : sigma};
+            }
             *(f32x4*)(a.out + pt * 4) = o;
         }
     } else {
@@ -314,7 +323,7 @@ void nerf_mlp_kernel(const MlpLaunch a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < a.out_ch) a.out[pt * a.out_ch + row] = o[r];
+                if (row < a.out_ch) a.out[pt * a.out_ch + row] = (bad & kBadXyz) ? __builtin_nanf("") : o[r];
             }
         }
     }

@@ -57,11 +57,17 @@ __device__ __forceinline__ void mma_one(f32x16& acc, const Frag4& f, const XT& x
 }
 
 // max with the partner lane of the other half-wave: v_permlane32_swap on two copies yields (lo, lo) and (hi, hi)
-// - a vector instruction, no trip through the LDS crossbar and no lgkmcnt wait
+// - a vector instruction, no trip through the LDS crossbar and no lgkmcnt wait. From inline asm: through
+// __builtin_amdgcn_permlane32_swap(u, u, ...) hipcc folds max(r[0], r[1]) to r[0] (it takes the two results of a swap
+// of equal inputs for equal), which silently made every lane use the LOWER half-wave's value - harmless while both
+// halves of a point have similar maxima, an fp16 overflow (NaN) when one row of the upper half dominates
+// (tests: test_mlp_precisions_vs_fp64, "one row x2^16").
 __device__ __forceinline__ float half_max(float m) {
-    const unsigned u = __builtin_bit_cast(unsigned, m);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    float a = m, b = m;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 // multiply a split tile by 2^d (exact while nothing leaves the fp16 range)
 __device__ __forceinline__ void rescale_tile(XT& x, int d) {
@@ -452,8 +458,17 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             const float r0 = row_dot4(y, bias0 + 128 * (8 * a.D + 22)) + lds_scalar(rb);
             const float r1 = row_dot4(y, bias0 + 128 * (8 * a.D + 26)) + lds_scalar(rb + 1);
             const float r2 = row_dot4(y, bias0 + 128 * (8 * a.D + 30)) + lds_scalar(rb + 2);
+            unsigned bad;     // raw inputs re-read here: a value kept across the view layer costs the step a register
+            {
+                f32x16 x0, x1, dd;
+                load_inputs<MODE, false, false>(a, pt, h, x0, x1, dd, nullptr, &bad);
+            }
             if (live && h == 0) {
                 f32x4 o = {r0, r1, r2, sigma};   // outputs = cat[rgb, alpha] (nerf.py:106)
+                if (bad) {                       // NaN / Inf inputs propagate as through F.relu (see kBadXyz)
+                    const float qnan = __builtin_nanf("");
+                    o = f32x4{qnan, qnan, qnan, (bad & kBadXyz) ? qnan : sigma};
+                }
                 *(f32x4*)(a.out + pt * 4) = o;
             }
         } else {
@@ -471,11 +486,17 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             Tile16 b = lds_tile_issue(bias0 + 128 * (8 * a.D));
             lds_tile_wait(b);
             const float c = lds_scalar(layer_tab + 4 * a.D) * pow2f(-pd.t_out);
+            unsigned bad;
+            {
+                f32x16 x0, x1, dd;
+                load_inputs<MODE, false, false>(a, pt, h, x0, x1, dd, nullptr, &bad);
+            }
             if (live) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < a.out_ch) a.out[pt * a.out_ch + row] = fmaf(o[r], c, b.q[r >> 2][r & 3]);
+                    if (row < a.out_ch)
+                        a.out[pt * a.out_ch + row] = (bad & kBadXyz) ? __builtin_nanf("") : fmaf(o[r], c, b.q[r >> 2][r & 3]);
                 }
             }
         }

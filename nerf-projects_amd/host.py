@@ -91,6 +91,20 @@ class Context:
         return int(self.lib.nerf_workspace_bytes(self.handle))
 
 
+def _warn_if_scale_bound_was_loose(ctx, where):
+    """The fp16-pair kernel counts (never hides) the cases in which its a-priori per-point scale bound was >= 2^12 too
+    wide for the weights at hand (include/nerf_mi355x.h, nerf_precision_status); surfaced at natural sync points."""
+    if ctx.get_precision() != "f16x2":
+        return 0
+    n = ctx.precision_status(reset=True)
+    if n:
+        import warnings
+        warnings.warn(f"{where}: the fp16-pair MLP kernel's output-scale bound was loose in {n} (wavefront, layer) "
+                      "cases since the last check, i.e. some activations kept fewer than 24 bits with these weights; "
+                      "use get_context().set_precision('f32') for them", RuntimeWarning, stacklevel=3)
+    return n
+
+
 _contexts = {}
 
 
@@ -867,6 +881,8 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
         if savedir is not None:
             write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))
     rgbs, disps = np.stack(rgbs, 0), np.stack(disps, 0)
+    if isinstance(render_kwargs.get('network_fn'), NeRF):
+        _warn_if_scale_bound_was_loose(render_kwargs['network_fn'].ctx, "render_path")
     if want_metrics:
         avg = {}
         for key, values in all_metrics.items():
@@ -1030,6 +1046,7 @@ class Adam:
 def save_checkpoint(path, global_step, network_fn, network_fine, optimizer):
     """The file the reference writes every ``i_weights`` iterations (nerf.ipynb:1290-1299) and reloads in
     ``create_nerf`` (:925-935)."""
+    _warn_if_scale_bound_was_loose(network_fn.ctx, "save_checkpoint")
     torch.save({'global_step': int(global_step),
                 'network_fn_state_dict': network_fn.state_dict(),
                 'network_fine_state_dict': network_fine.state_dict() if network_fine is not None else None,

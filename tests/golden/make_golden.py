@@ -580,6 +580,94 @@ def gold_llff_pose_math():
          sph_render=sp_render, sph_bds=sp_bds)
 
 
+def gold_tiny_scene():
+    """A tiny Blender scene and a tiny LLFF scene committed as FILES (tests/golden/tiny_scene/), encoded with Pillow -
+    the library behind the reference's ``imageio.imread`` - plus what the reference's loaders make of them. The
+    loader modules themselves cannot be imported here (imageio / cv2 are absent), so the expected arrays are built
+    from the reference's lines with Pillow as the decoder: pixels ``(np.array(imgs) / 255.).astype(np.float32)``
+    (load_blender.py:64), ``imread(f)[..., :3] / 255.`` (load_llff.py:131); poses by the reference's OWN pose functions
+    (executed from source as in gold_llff_pose_math) around the three glue lines of load_llff_data restated here
+    (axis fix-up :252, bd_factor rescale :258-261, hold-out view :308-309)."""
+    import ast
+    import shutil
+    from PIL import Image
+    root = os.path.join(HERE, "tiny_scene")
+    shutil.rmtree(root, ignore_errors=True)
+    rs = np.random.RandomState(108)
+    out = {}
+    # ---- Blender: transforms_{train,val,test}.json + RGBA PNGs
+    bl = os.path.join(root, "blender")
+    H = W = 16
+    angle = 0.6911112070083618
+    yy, xx = np.mgrid[0:H, 0:W]
+    k = 0
+    for split, n_img in (("train", 3), ("val", 1), ("test", 2)):
+        os.makedirs(os.path.join(bl, split))
+        frames = []
+        for i in range(n_img):
+            img = np.stack([(xx * 16 + 7 * k) % 256, (yy * 16 + 31 * k) % 256, (xx * yy + 5 * k) % 256,
+                            np.where((xx - 8) ** 2 + (yy - 8) ** 2 < 30 + 4 * k, 255, 0)], -1).astype(np.uint8)
+            img[..., :3] ^= rs.randint(0, 8, size=(H, W, 3)).astype(np.uint8)
+            Image.fromarray(img, "RGBA").save(os.path.join(bl, split, f"r_{i}.png"))
+            frames.append({"file_path": f"./{split}/r_{i}", "transform_matrix":
+                           synthetic.pose_spherical(37.0 * k - 90.0, -30.0, 4.0).tolist()})
+            out[f"blender_px_{split}_{i}"] = np.asarray(Image.open(os.path.join(bl, split, f"r_{i}.png")))
+            k += 1
+        json.dump({"camera_angle_x": angle, "frames": frames}, open(os.path.join(bl, f"transforms_{split}.json"), "w"),
+                  indent=1)
+    order = [("train", 0), ("train", 1), ("train", 2), ("val", 0), ("test", 0), ("test", 1)]
+    out["blender_imgs"] = (np.array([out[f"blender_px_{s_}_{i}"] for s_, i in order]) / 255.).astype(np.float32)
+    out["blender_focal"] = .5 * W / np.tan(.5 * angle)
+    # ---- LLFF: poses_bounds.npy, images/*.jpg (full size), images_2/*.png (what factor=2 reads)
+    ll = os.path.join(root, "llff")
+    os.makedirs(os.path.join(ll, "images"))
+    os.makedirs(os.path.join(ll, "images_2"))
+    g = np.load(os.path.join(HERE, "llff_pose_math.npz"))
+    n_img = 5
+    poses_raw, bds_raw = g["poses"][:n_img].astype(np.float64), g["bds"][:n_img].astype(np.float64)
+    np.save(os.path.join(ll, "poses_bounds.npy"), np.concatenate([poses_raw.reshape(n_img, 15), bds_raw], 1))
+    Hf, Wf = 16, 24
+    yy, xx = np.mgrid[0:Hf, 0:Wf]
+    small = []
+    for i in range(n_img):
+        img = np.stack([(xx * 10 + 20 * i) % 256, (yy * 15 + 9 * i) % 256, ((xx + yy) * 6 + i) % 256], -1).astype(np.uint8)
+        Image.fromarray(img, "RGB").save(os.path.join(ll, "images", f"img_{i:03d}.jpg"), quality=92)
+        half = Image.fromarray(img, "RGB").resize((Wf // 2, Hf // 2), Image.BOX)
+        half.save(os.path.join(ll, "images_2", f"img_{i:03d}.png"))
+        small.append(np.asarray(Image.open(os.path.join(ll, "images_2", f"img_{i:03d}.png"))))
+        out[f"llff_jpg_{i}"] = np.asarray(Image.open(os.path.join(ll, "images", f"img_{i:03d}.jpg")))
+    out["llff_images"] = np.stack([im[..., :3] / 255. for im in small], 0).astype(np.float32)
+    # the reference's own pose functions (numpy only), executed from its source
+    tree = ast.parse(open(os.path.join(REF, "load_llff.py")).read())
+    want = {"normalize", "viewmatrix", "ptstocam", "poses_avg", "render_path_spiral", "recenter_poses", "spherify_poses"}
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[nd for nd in tree.body if isinstance(nd, ast.FunctionDef) and nd.name in want],
+                            type_ignores=[]), "load_llff.py", "exec"), ns)
+    poses = np.moveaxis(poses_raw.reshape(n_img, 3, 5), 0, -1).copy()                    # [3,5,N] as _load_data returns
+    poses[0, 4, :], poses[1, 4, :] = Hf // 2, Wf // 2
+    poses[2, 4, :] = poses[2, 4, :] * 1. / 2
+    bds = bds_raw.T.copy()
+    poses = np.concatenate([poses[:, 1:2, :], -poses[:, 0:1, :], poses[:, 2:, :]], 1)      # load_llff.py:252
+    poses = np.moveaxis(poses, -1, 0).astype(np.float32)
+    bds = np.moveaxis(bds, -1, 0).astype(np.float32)
+    sc = 1. / (bds.min() * .75)                                                            # :258-261
+    poses[:, :3, 3] *= sc
+    bds *= sc
+    poses = ns["recenter_poses"](poses)
+    c2w = ns["poses_avg"](poses)
+    up = ns["normalize"](poses[:, :3, 1].sum(0))
+    close_depth, inf_depth = bds.min() * .9, bds.max() * 5.
+    focal = 1. / ((1. - .75) / close_depth + .75 / inf_depth)
+    rads = np.percentile(np.abs(poses[:, :3, 3]), 90, 0)
+    spiral = ns["render_path_spiral"](c2w, up, rads, focal, close_depth * .2, zrate=.5, rots=2, N=120)
+    out["llff_poses"] = poses.astype(np.float32)
+    out["llff_bds"] = bds
+    out["llff_render_poses"] = np.array(spiral).astype(np.float32)
+    c2w = ns["poses_avg"](poses)
+    out["llff_i_test"] = np.argmin(np.sum(np.square(c2w[:3, 3] - poses[:, :3, 3]), -1))    # :308-309
+    save("tiny_scene", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -602,3 +690,4 @@ if __name__ == "__main__":
     gold_train_variants()
     gold_train_adam_state()
     gold_llff_pose_math()
+    gold_tiny_scene()

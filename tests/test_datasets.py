@@ -135,3 +135,59 @@ def test_load_llff_data(tmp_path):
     assert rp_sph.shape == (120, 3, 5)
     with pytest.raises(RuntimeError):
         datasets.load_llff_data(str(tmp_path), factor=4)           # images_4 absent and no mogrify here
+
+
+# ---- the committed tiny scene (tests/golden/tiny_scene/, written by make_golden.py with Pillow = imageio's decoder) ----
+
+SCENE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_scene")
+
+
+def test_png_reader_agrees_with_pillow_on_the_scene():
+    """The pure-Python PNG reader (used only where Pillow is missing) against the pixels Pillow decoded when the
+    fixture was made, for every PNG of the scene; read_image against the same, JPEG included."""
+    g = load_golden("tiny_scene")
+    for split, n in (("train", 3), ("val", 1), ("test", 2)):
+        for i in range(n):
+            f = os.path.join(SCENE, "blender", split, f"r_{i}.png")
+            assert np.array_equal(datasets.read_png(f), g[f"blender_px_{split}_{i}"])
+            assert np.array_equal(datasets.read_image(f), g[f"blender_px_{split}_{i}"])
+    for i in range(5):
+        jpg = datasets.read_image(os.path.join(SCENE, "llff", "images", f"img_{i:03d}.jpg"))
+        assert jpg.shape == (16, 24, 3) and jpg.dtype == np.uint8
+        assert np.abs(jpg.astype(int) - g[f"llff_jpg_{i}"].astype(int)).max() <= 1      # same libjpeg: identical here
+
+
+def test_blender_loader_on_the_committed_scene():
+    g = load_golden("tiny_scene")
+    imgs, poses, render_poses, hwf, i_split = datasets.load_blender_data(os.path.join(SCENE, "blender"))
+    assert imgs.dtype == np.float32 and np.array_equal(imgs, g["blender_imgs"])       # load_blender.py:64, RGBA kept
+    assert [list(s) for s in i_split] == [[0, 1, 2], [3], [4, 5]]
+    assert hwf[:2] == [16, 16] and hwf[2] == float(g["blender_focal"])
+    assert poses.shape == (6, 4, 4) and poses.dtype == np.float32
+    np.testing.assert_allclose(poses[3], synthetic.pose_spherical(37.0 * 3 - 90.0, -30.0, 4.0), atol=1e-6)
+    half, _, _, hwf_h, _ = datasets.load_blender_data(os.path.join(SCENE, "blender"), half_res=True)
+    assert half.shape == (6, 8, 8, 4) and half.dtype == np.float64 and hwf_h == [8, 8, hwf[2] / 2.]
+    a = g["blender_imgs"][2]
+    want = ((a[0::2, 0::2] + a[0::2, 1::2]) + a[1::2, 0::2] + a[1::2, 1::2]) * np.float32(0.25)   # INTER_AREA, float32
+    assert np.array_equal(half[2], want.astype(np.float64))
+
+
+def test_llff_loader_on_the_committed_scene():
+    """load_llff_data end to end: images through the decoder, poses through the reference's own pose functions
+    (the fixture ran them), the glue lines in between restated once in make_golden.py and once in datasets.py."""
+    g = load_golden("tiny_scene")
+    images, poses, bds, render_poses, i_test = datasets.load_llff_data(os.path.join(SCENE, "llff"), factor=2)
+    assert images.dtype == np.float32 and np.array_equal(images, g["llff_images"])
+    np.testing.assert_allclose(poses, g["llff_poses"], atol=2e-6)
+    np.testing.assert_allclose(bds, g["llff_bds"], atol=1e-6)
+    np.testing.assert_allclose(render_poses, g["llff_render_poses"], atol=2e-6)
+    assert int(i_test) == int(g["llff_i_test"])
+    assert poses[0, 0, 4] == 8 and poses[0, 1, 4] == 12 and abs(poses[0, 2, 4] - 407.5 / 2) < 1e-3
+    # the full-size folder holds JPEGs (what LLFF captures ship): factor=None reads them
+    raw = datasets._load_data(os.path.join(SCENE, "llff"), factor=None)
+    assert raw[2].shape == (16, 24, 3, 5) and raw[0][2, 4, 0] == 407.5
+    # height= / width= forms (load_llff.py:77-87): the folder name carries the size derived from the full-size images
+    for kw in (dict(height=8), dict(width=12)):
+        with pytest.raises(RuntimeError) as e:
+            datasets._load_data(os.path.join(SCENE, "llff"), **kw)
+        assert "images_12x8" in str(e.value)
