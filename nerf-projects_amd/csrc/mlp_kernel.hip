@@ -222,8 +222,33 @@ __device__ __forceinline__ void activate(f32x16 (&dst)[8], const f32x16 (&src)[8
 #endif
 }
 
+// Training forward (STORE): N activation tiles of this wave's 32 points to a row-major [points, channels] buffer. A lane
+// holds, per tile t and register quad q, the four consecutive features 32 t + 8 q + 4 h .. + 3 of its point; the two
+// half-waves of a point write adjacent 16-byte pieces, so one store instruction covers 32 bytes of each of 32 rows.
+// Rows of the concat buffers ([gamma(x) | h], [feature | gamma(dir)]) are not 16-byte aligned: dword stores there.
+template <int N>
+__device__ __forceinline__ void store_tiles(float* base, int ld, const f32x16 (&t)[8], int64_t pt, int h, bool live) {
+    if (base == nullptr || !live) return;
+    float* row = base + pt * (int64_t)ld + 4 * h;
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);   // wave-uniform
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float* p = row + 32 * i + 8 * q;
+            if (vec) {
+                *(f32x4*)p = f32x4{t[i][4 * q], t[i][4 * q + 1], t[i][4 * q + 2], t[i][4 * q + 3]};
+            } else {
+                p[0] = t[i][4 * q];
+                p[1] = t[i][4 * q + 1];
+                p[2] = t[i][4 * q + 2];
+                p[3] = t[i][4 * q + 3];
+            }
+        }
+}
+
 // ---- the kernel -------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool STORE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void nerf_mlp_kernel(const MlpLaunch a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -248,6 +273,7 @@ void nerf_mlp_kernel(const MlpLaunch a) {
     const int64_t tile0 = tile * kPointsPerGroup + wave * kPointsPerWave;
     const int64_t pt_raw = tile0 + (lane & 31);
     const int64_t pt = pt_raw < a.n_points ? pt_raw : a.n_points - 1;   // clamp: padded lanes recompute the last point
+    const bool live = pt_raw < a.n_points;
 
     f32x16 x0, x1, dd;
     load_inputs<MODE>(a, pt, h, x0, x1, dd);
@@ -259,6 +285,7 @@ void nerf_mlp_kernel(const MlpLaunch a) {
     chunk_ktile8(pipe, cur, acc, x0);
     chunk_ktile8(pipe, cur, acc, x1);
     activate<8, true>(hid, acc);
+    if constexpr (STORE) store_tiles<8>(a.st.h[0], a.st.h_ld[0], hid, pt, h, live);
 
     // trunk layers 1..D-1, then (with viewdirs) feature_linear as layer D without ReLU
     const int n_layers = a.use_viewdirs ? a.D + 1 : a.D;
@@ -283,12 +310,13 @@ void nerf_mlp_kernel(const MlpLaunch a) {
             // row_dot above and only keeps the ring turning
             consume_chunk<8>(pipe, cur, [&](auto, auto, const Frag16&) {});
             activate<8, false>(hid, acc);
+            if constexpr (STORE) store_tiles<8>(a.st.feat, a.st.feat_ld, hid, pt, h, live);
         } else {
             activate<8, true>(hid, acc);
+            if constexpr (STORE) store_tiles<8>(a.st.h[i], a.st.h_ld[i], hid, pt, h, live);
         }
     }
 
-    const bool live = pt_raw < a.n_points;
     unsigned bad;      // NaN / Inf inputs propagate as through F.relu (mlp_inputs.h, kBadXyz): raw inputs re-read here
     {
         f32x16 t0, t1, t2;
@@ -301,6 +329,7 @@ void nerf_mlp_kernel(const MlpLaunch a) {
         for (int kp = 0; kp < 4; ++kp) chunk_pair4(pipe, cur, acc, hid[2 * kp], hid[2 * kp + 1]);
         chunk_ktile4(pipe, cur, acc, dd);
         activate<4, true>(hid, acc);
+        if constexpr (STORE) store_tiles<4>(a.st.hv, a.st.hv_ld, hid, pt, h, live);
         // rgb_linear (nerf.py:101): three output rows over the 128-wide view layer, as dot products
         const float* rb = bias_lds + (8 * a.D + 13) * 32;
         const float r0 = row_dot<4>(hid, bias_lds, 8 * a.D + 22, h) + rb[0];
@@ -349,28 +378,21 @@ hipError_t launch_mlp(const MlpLaunch& a, int mode, hipStream_t s) {
     }
     const dim3 grid((unsigned)(tiles < n_cu[dev] ? tiles : n_cu[dev])), block(256);
     const size_t lds = kBiasLdsBytes + kRing * kChunkBytes;
-    // 112 KiB of dynamic LDS is above the 64 KiB default cap: raise it once per device and mode
-    static bool raised[64][3] = {};
+    static bool raised[64][4] = {};
     if (mode < 0 || mode > 2) return hipErrorInvalidValue;
-    if (dev < 64 && !raised[dev][mode]) {
-        const void* fn = mode == kInputEmbedded ? (const void*)nerf_mlp_kernel<kInputEmbedded>
-                         : mode == kInputPoints ? (const void*)nerf_mlp_kernel<kInputPoints>
-                                                : (const void*)nerf_mlp_kernel<kInputRays>;
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (a.store && mode != kInputRays) return hipErrorInvalidValue;      // the training forward feeds ray records
+    typedef void (*kernel_t)(const MlpLaunch);
+    static const kernel_t table[4] = {nerf_mlp_kernel<kInputEmbedded>, nerf_mlp_kernel<kInputPoints>,
+                                      nerf_mlp_kernel<kInputRays>, nerf_mlp_kernel<kInputRays, true>};
+    static_assert(kInputEmbedded == 0 && kInputPoints == 1 && kInputRays == 2, "kernel table order");
+    const int which = a.store ? 3 : mode;
+    // 112 KiB of dynamic LDS is above the 64 KiB default cap: raise it once per device and kernel
+    if (!raised[dev][which]) {
+        e = hipFuncSetAttribute((const void*)table[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        raised[dev][mode] = true;
+        raised[dev][which] = true;
     }
-    switch (mode) {
-        case kInputEmbedded:
-            hipLaunchKernelGGL(nerf_mlp_kernel<kInputEmbedded>, grid, block, lds, s, a);
-            break;
-        case kInputPoints:
-            hipLaunchKernelGGL(nerf_mlp_kernel<kInputPoints>, grid, block, lds, s, a);
-            break;
-        default:
-            hipLaunchKernelGGL(nerf_mlp_kernel<kInputRays>, grid, block, lds, s, a);
-            break;
-    }
+    hipLaunchKernelGGL(table[which], grid, block, lds, s, a);
     return hipGetLastError();
 }
 

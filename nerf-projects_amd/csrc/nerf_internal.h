@@ -86,6 +86,17 @@ struct PackedNet {
 
 enum MlpInputMode { kInputEmbedded = 0, kInputPoints = 1, kInputRays = 2 };
 
+// Training forward pass through the fused fp32 kernel: where the activations autograd would keep are written
+// (row-major [points, channels], any row stride; nullptr = not kept). See train_api.cpp forward_pass.
+struct MlpStore {
+    float* h[kMaxDepth];     // post-ReLU output of trunk layer i
+    int h_ld[kMaxDepth];
+    float* feat;             // feature_linear output (no ReLU), 256 wide
+    int feat_ld;
+    float* hv;               // views_linears[0] output (post ReLU), 128 wide
+    int hv_ld;
+};
+
 struct MlpLaunch {
     const float* stream;
     const uint32_t* stream_h2;   // NERF_PRECISION_F16X2 only
@@ -115,6 +126,8 @@ struct MlpLaunch {
     int ray_ld;
     const float* z_vals;
     float* out;
+    int store;               // 1: also write the activations named in `st` (fp32 kernel only)
+    MlpStore st;
 };
 
 // host-side packer (pack_weights.cpp)

@@ -5,6 +5,7 @@
 // for one batch of rays, entirely on the device. The caller owns the RNG (t_rand / u_rand / noise),
 // the ray batching and the learning-rate schedule.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "ctx_internal.h"
@@ -111,9 +112,65 @@ void carve_pass(Arena& ar, Pass& ps) {
     ps.g_hv = ar.take((size_t)P * (a.W / 2));
 }
 
+// The training forward pass. NERF_TRAIN_GEMM_FORWARD=1 in the environment (or a network the fused kernel's store
+// path does not cover) selects the layer-by-layer GEMM chain below; the default is ONE launch of the fused fp32
+// encode+MLP kernel (mlp_kernel.hip, STORE variant: weights streamed by LDS-DMA, activations chained in registers) that
+// also writes what autograd would keep - every trunk layer's post-ReLU output, the feature vector, the view layer's
+// output - into the same buffers the GEMM chain fills, so the backward pass below is unchanged. Same arithmetic class
+// (v_mfma_f32_32x32x2_f32, fp32 accumulate), a different order of the 256 products of a sum.
+bool gemm_forward_requested() {
+    static const bool on = [] {
+        const char* e = getenv("NERF_TRAIN_GEMM_FORWARD");
+        return e && *e && *e != '0';
+    }();
+    return on;
+}
+
+int forward_pass_fused(Pass& ps, const float* rays, int ray_ld, const float* z, hipStream_t s) {
+    const PackedNet& net = *ps.net;
+    const nerf_arch& a = net.arch;
+    const int Lx = (a.input_ch - 3) / 6, Lv = a.use_viewdirs ? (a.input_ch_views - 3) / 6 : 0;
+    // the encodings are still written out: they are the X of dW = dY^T X for layer 0, the skip layer and the view layer
+    HIP_TRY(launch_embed_train(rays, ray_ld, z, ps.P, ps.S, Lx, Lv, ps.in[0], ps.in_ld[0], ps.vcat, ps.vcat_ld, a.W, s));
+    for (int i = 1; i < a.D; ++i)
+        if ((net.skip_in_mask >> i) & 1)
+            HIP_TRY(launch_embed_train(rays, ray_ld, z, ps.P, ps.S, Lx, 0, ps.in[i], ps.in_ld[i], nullptr, 0, 0, s));
+    MlpLaunch m{};
+    m.stream = net.d_stream;
+    m.bias = net.d_bias;
+    m.n_chunks = net.n_chunks;
+    m.n_bias_tiles = net.n_bias_tiles;
+    m.D = a.D;
+    m.skip_in_mask = net.skip_in_mask;
+    m.use_viewdirs = a.use_viewdirs;
+    m.out_ch = net.out_ch;
+    m.in_ch = a.input_ch;
+    m.in_ch_views = a.input_ch_views;
+    m.n_points = ps.P;
+    m.samples_per_ray = ps.S;
+    m.rays = rays;
+    m.ray_ld = ray_ld;
+    m.z_vals = z;
+    m.out = ps.raw;
+    m.store = 1;
+    for (int i = 0; i < a.D; ++i) {
+        m.st.h[i] = ps.h[i];
+        m.st.h_ld[i] = ps.h_ld[i];
+    }
+    if (a.use_viewdirs) {
+        m.st.feat = ps.vcat;
+        m.st.feat_ld = ps.vcat_ld;
+        m.st.hv = ps.hv;
+        m.st.hv_ld = a.W / 2;
+    }
+    HIP_TRY(launch_mlp(m, kInputRays, s));
+    return NERF_OK;
+}
+
 int forward_pass(Pass& ps, const float* rays, int ray_ld, const float* z, hipStream_t s) {
     const PackedNet& net = *ps.net;
     const nerf_arch& a = net.arch;
+    if (!gemm_forward_requested() && ps.C == net.out_ch && a.D <= kMaxDepth) return forward_pass_fused(ps, rays, ray_ld, z, s);
     const float* wt = net.train.d_wt;
     const float* prm = net.d_params;
     const int Lx = (a.input_ch - 3) / 6, Lv = a.use_viewdirs ? (a.input_ch_views - 3) / 6 : 0;

@@ -487,31 +487,43 @@ def gold_train():
 def gold_train_adam_state():
     """torch.optim.Adam's state after the two iterations of gold_train (same inputs, same RNG): every 61st element of
     exp_avg / exp_avg_sq per parameter and the step count - what 'optimizer_state_dict' of a checkpoint carries
-    (nerf.ipynb:1290-1299)."""
+    (nerf.ipynb:1290-1299). The same two iterations are also run by the reference in float64 (``*.f64`` arrays): the
+    second iteration resamples along rays whose weights moved with the first update, so the moments of the FINE network
+    differ between any two fp32 evaluations by far more than rounding; the reference's own fp32-vs-fp64 distance is the
+    yardstick the test uses."""
     g = np.load(os.path.join(HERE, "render_rays_lego.npz"))
-    rays = torch.from_numpy(g["rays"][:32])
     rs = np.random.RandomState(106)
-    target = torch.from_numpy(rs.uniform(0, 1, size=(32, 3)).astype(np.float32))
-    net_c, net_f = ref_pair(0)
-    net_c.train(); net_f.train()
-    e_fn, _ = ref_embedder.get_embedder(10, 0)
-    ed_fn, _ = ref_embedder.get_embedder(4, 0)
-    params = list(net_c.parameters()) + list(net_f.parameters())
-    opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999))
-    kw = dict(N_samples=64, N_importance=128, retraw=True, white_bkgd=True, perturb=1.0, raw_noise_std=1.0,
-              pytest=True)
-    for it in range(2):
-        ret = NS["render_rays"](rays, net_c, query_fn(e_fn, ed_fn), network_fine=net_f, **kw)
-        opt.zero_grad()
-        loss = ref_helpers.img2mse(ret["rgb_map"], target) + ref_helpers.img2mse(ret["rgb0"], target)
-        loss.backward()
-        opt.step()
-    sd = opt.state_dict()
-    out = {"n_params": len(sd["state"]), "step": float(sd["state"][0]["step"]),
-           "group_keys": np.array(sorted(sd["param_groups"][0].keys()))}
-    for i, st in sd["state"].items():
-        out[f"exp_avg.{i}"] = n(st["exp_avg"]).reshape(-1)[::61].copy()
-        out[f"exp_avg_sq.{i}"] = n(st["exp_avg_sq"]).reshape(-1)[::61].copy()
+    target_np = rs.uniform(0, 1, size=(32, 3)).astype(np.float32)
+    out = {}
+    for tag, dtype in (("", torch.float32), (".f64", torch.float64)):
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            rays = torch.from_numpy(g["rays"][:32]).to(dtype)
+            target = torch.from_numpy(target_np).to(dtype)
+            net_c, net_f = ref_pair(0, dtype)
+            net_c.train(); net_f.train()
+            e_fn, _ = ref_embedder.get_embedder(10, 0)
+            ed_fn, _ = ref_embedder.get_embedder(4, 0)
+            params = list(net_c.parameters()) + list(net_f.parameters())
+            opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999))
+            kw = dict(N_samples=64, N_importance=128, retraw=True, white_bkgd=True, perturb=1.0, raw_noise_std=1.0,
+                      pytest=True)
+            for it in range(2):
+                ret = NS["render_rays"](rays, net_c, query_fn(e_fn, ed_fn), network_fine=net_f, **kw)
+                opt.zero_grad()
+                loss = ref_helpers.img2mse(ret["rgb_map"], target) + ref_helpers.img2mse(ret["rgb0"], target)
+                loss.backward()
+                opt.step()
+            sd = opt.state_dict()
+        finally:
+            torch.set_default_dtype(old)
+        if tag == "":
+            out.update({"n_params": len(sd["state"]), "step": float(sd["state"][0]["step"]),
+                        "group_keys": np.array(sorted(sd["param_groups"][0].keys()))})
+        for i, st in sd["state"].items():
+            out[f"exp_avg.{i}{tag}"] = n(st["exp_avg"]).reshape(-1)[::61].copy()
+            out[f"exp_avg_sq.{i}{tag}"] = n(st["exp_avg_sq"]).reshape(-1)[::61].copy()
     save("train_step_adam", **out)
 
 

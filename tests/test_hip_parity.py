@@ -927,9 +927,12 @@ def test_checkpoint_round_trip_with_optimizer_state(N, weights_pair, tmp_path):
     for i in range(48):
         for name in ("exp_avg", "exp_avg_sq"):
             got, want = sd["state"][i][name].numpy().reshape(-1)[::61], ga[f"{name}.{i}"]
-            # the fine network (i >= 24) inherits the resampling sensitivity of its second forward pass
-            tol = (1e-4 if i < 24 else 2e-3) * (np.abs(want).max() + 1e-30)
-            assert np.abs(got - want).max() <= tol, (name, i)
+            # 1e-4 of the tensor's largest entry, or - the fine network (i >= 24) inherits the resampling sensitivity of
+            # the second iteration's forward pass - 3x the distance between the reference's own fp32 and fp64 runs
+            # of the same two iterations (up to 2 % of the largest entry; tests/golden/make_golden.py)
+            ref_gap = np.abs(want - ga[f"{name}.{i}.f64"]).max()
+            tol = max(1e-4 * (np.abs(want).max() + 1e-30), 3 * ref_gap)
+            assert np.abs(got - want).max() <= tol, (name, i, np.abs(got - want).max(), tol)
     # torch accepts the layout
     shapes = [tuple(v.shape) for m in (net_c, net_f) for v in m.state_dict().values()]
     t_opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(s)) for s in shapes], lr=1e-3)
