@@ -108,7 +108,7 @@ namespace {
 void free_net(PackedNet& n) {
     for (void* p : {(void*)n.d_stream, (void*)n.d_bias, (void*)n.d_params, (void*)n.train.d_grad, (void*)n.train.d_m,
                     (void*)n.train.d_v, (void*)n.train.d_wt, (void*)n.train.d_stream_table,
-                    (void*)n.train.d_bias_table, (void*)n.d_stream_h2, (void*)n.d_descale, (void*)n.d_chunk_layer,
+                    (void*)n.train.d_bias_table, (void*)n.train.d_bwd_table, (void*)n.train.d_stream_bwd, (void*)n.d_stream_h2, (void*)n.d_descale, (void*)n.d_chunk_layer,
                     (void*)n.d_chunk_max, (void*)n.d_gain})
         if (p) (void)hipFree(p);
     n = PackedNet{};
@@ -301,6 +301,21 @@ int nerf_load_weights(nerf_ctx* c, int slot, const nerf_arch* arch, const float*
         free(ts);
         free(tb);
         net.n_params = total;
+        // index table of the fused backward-data kernel's stream (training; view-dependent networks only)
+        net.bwd_table.clear();
+        if (arch->use_viewdirs) {
+            float* tsb = nullptr;
+            int nbc = 0;
+            rc = pack_backward_stream(*arch, fake_ptrs.data(), mask, &tsb, &nbc);
+            if (rc != NERF_OK) {
+                free(hs);
+                free(hb);
+                return rc;
+            }
+            net.bwd_table.resize((size_t)nbc * kChunkFloats);
+            for (size_t i = 0; i < net.bwd_table.size(); ++i) net.bwd_table[i] = (int)tsb[i] - 1;
+            free(tsb);
+        }
     }
     if (e == hipSuccess) e = hipMalloc((void**)&net.d_params, net.n_params * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(net.d_params, flat.data(), net.n_params * sizeof(float), hipMemcpyHostToDevice);

@@ -69,9 +69,17 @@ __device__ __forceinline__ int ring_next(int b, int k) {
 __device__ __forceinline__ void prefetch_chunk(const Pipe& p, int chunk, int slot) {
     const char* g = p.stream + (size_t)chunk * kChunkBytes + p.wave * 8192 + p.lane * 16;
     char* l = p.lds + slot * kChunkBytes + p.wave * 8192;
+    // two address pairs per chunk, the pieces selected by the instruction's immediate offset (<= 3 KiB): with one pointer
+    // per piece hipcc precomputes (and spills) eight 64-bit addresses for every unrolled chunk
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-        __builtin_amdgcn_global_load_lds(GLB_PTR(g + i * 1024), LDS_PTR(l + i * 1024), 16, 0, 0);
+    for (int half = 0; half < 2; ++half) {
+        const char* gh = g + half * 4096;
+        char* lh = l + half * 4096;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(gh), LDS_PTR(lh), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(gh), LDS_PTR(lh), 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(gh), LDS_PTR(lh), 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(gh), LDS_PTR(lh), 16, 3072, 0);
+    }
 }
 
 __device__ __forceinline__ const f32x4* ring_frags(const Pipe& p, int slot) {
@@ -229,6 +237,9 @@ __device__ __forceinline__ void activate(f32x16 (&dst)[8], const f32x16 (&src)[8
 template <int N>
 __device__ __forceinline__ void store_tiles(float* base, int ld, const f32x16 (&t)[8], int64_t pt, int h, bool live) {
     if (base == nullptr || !live) return;
+    // wave-uniform base + 32-bit element offset (the buffers of a pass stay below 2^32 bytes: train_api.cpp checks):
+    // one VGPR per row address instead of a 64-bit pair per buffer, which hipcc otherwise precomputes for every
+    // buffer of the launch record and spills
     float* row = base + pt * (int64_t)ld + 4 * h;
     const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);   // wave-uniform
 #pragma unroll
@@ -361,6 +372,166 @@ void nerf_mlp_kernel(const MlpLaunch a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- fused backward-data pass (training) --------------------------------------------------
+// The chain loss.backward() runs through the MLP, d raw -> d(pre-activation of every layer), in the forward kernel's
+// orientation: d H_in^T [in x points] = W^T [in x out] * d Z^T, the transposed weights streamed by LDS-DMA
+// (pack_backward_stream), the running gradient chained in registers from layer to layer. Per layer the only memory
+// traffic is the ReLU mask (the post-ReLU activation the forward pass kept: 1 KB per point) and the masked gradient
+// written for the dW GEMM (gemm_tn, dW = dZ^T X): 2 KB per point and layer against 131 kFLOP.
+//   d(view pre)  = (d rgb . W_rgb) * [hv > 0]                       vector dot products, W_rgb rows from the bias block
+//   d feature    = W_views[:, :W]^T d(view pre)                     4 chunks
+//   d h_{D-1}    = W_feature^T d feature + d sigma * w_alpha        8 chunks + a rank-1 update
+//   d z_i        = d h_i * [h_i > 0];  d h_{i-1} = W_i[:, hidden]^T d z_i      8 chunks per trunk layer
+template <int N>
+__device__ __forceinline__ void load_tiles(const float* base, int ld, f32x16 (&t)[8], int64_t pt, int h) {
+    const float* row = base + (uint32_t)((uint32_t)pt * (uint32_t)ld + 4u * (uint32_t)h);
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);   // wave-uniform
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* p = row + 32 * i + 8 * q;
+            if (vec) {
+                const f32x4 v = *(const f32x4*)p;
+                t[i][4 * q] = v[0];
+                t[i][4 * q + 1] = v[1];
+                t[i][4 * q + 2] = v[2];
+                t[i][4 * q + 3] = v[3];
+            } else {
+                t[i][4 * q] = p[0];
+                t[i][4 * q + 1] = p[1];
+                t[i][4 * q + 2] = p[2];
+                t[i][4 * q + 3] = p[3];
+            }
+        }
+}
+// g *= [post-ReLU activation > 0], the activation read from `base`
+template <int N>
+__device__ __forceinline__ void mask_tiles(f32x16 (&dst)[8], const f32x16 (&g)[8], const float* base, int ld, int64_t pt,
+                                           int h) {
+    const float* row = base + (uint32_t)((uint32_t)pt * (uint32_t)ld + 4u * (uint32_t)h);
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* p = row + 32 * i + 8 * q;
+            f32x4 v;
+            if (vec) v = *(const f32x4*)p;
+            else v = f32x4{p[0], p[1], p[2], p[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[i][4 * q + e] = v[e] > 0.0f ? g[i][4 * q + e] : 0.0f;
+        }
+}
+template <int N>
+__device__ __forceinline__ void zero_tiles(f32x16 (&t)[8]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[i][r] = 0.0f;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* bias_lds = (float*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5;
+
+    Pipe pipe{(const char*)b.stream, smem + kBiasLdsBytes, 0, 0, b.n_chunks, wave, lane};
+    prefetch_chunk(pipe, 0, 0);
+    prefetch_chunk(pipe, b.n_chunks > 1 ? 1 : 0, 1);
+    for (int i = threadIdx.x; i < b.n_bias_tiles * kBiasTileFloats; i += 256) bias_lds[i] = b.bias[i];
+    __syncthreads();
+    Frag16 cur = read_frags(ring_frags(pipe, 0), 0);
+
+    const int64_t n_tiles = (b.n_points + kPointsPerGroup - 1) / kPointsPerGroup;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        pipe.c = 0;
+        const int64_t pt_raw = tile * kPointsPerGroup + wave * kPointsPerWave + (lane & 31);
+        const int64_t pt = pt_raw < b.n_points ? pt_raw : b.n_points - 1;
+        const bool live = pt_raw < b.n_points;
+        const float* dr = b.d_raw + pt * b.C;
+        const float d0 = dr[0], d1 = dr[1], d2 = dr[2], dsig = dr[3];
+
+        f32x16 hid[8], acc[8];
+        // d(view pre-activation): rgb_linear^T (3 rows, per-register weights: bias-block tiles 8D+22+4c+t) and the mask
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x16 w0 = *(const f32x16*)(bias_lds + ((8 * b.D + 22 + t) * 2 + h) * 16);
+            const f32x16 w1 = *(const f32x16*)(bias_lds + ((8 * b.D + 26 + t) * 2 + h) * 16);
+            const f32x16 w2 = *(const f32x16*)(bias_lds + ((8 * b.D + 30 + t) * 2 + h) * 16);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(d2, w2[r], fmaf(d1, w1[r], d0 * w0[r]));
+        }
+        mask_tiles<4>(hid, acc, b.fwd.hv, b.fwd.hv_ld, pt, h);
+        store_tiles<4>(b.out.hv, b.out.hv_ld, hid, pt, h, live);
+        __builtin_amdgcn_sched_barrier(0);     // keep the stores (and their addresses) here: spread into the chunk's
+                                               // MFMAs hipcc keeps one spilled 64-bit address per store alive
+
+        // d feature = W_views[:, :W]^T d(view pre-activation)
+        zero_tiles<8>(acc);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) chunk_ktile8(pipe, cur, acc, hid[kt]);
+        activate<8, false>(hid, acc);
+        store_tiles<8>(b.out.feat, b.out.feat_ld, hid, pt, h, live);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // d h_{D-1} = W_feature^T d feature + d sigma * w_alpha (alpha row: bias-block tiles 8D+14+t), then its mask
+        zero_tiles<8>(acc);
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) chunk_ktile8(pipe, cur, acc, hid[kt]);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const f32x16 wa = *(const f32x16*)(bias_lds + ((8 * b.D + 14 + t) * 2 + h) * 16);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(dsig, wa[r], acc[t][r]);
+        }
+        mask_tiles<8>(hid, acc, b.fwd.h[b.D - 1], b.fwd.h_ld[b.D - 1], pt, h);
+        store_tiles<8>(b.out.h[b.D - 1], b.out.h_ld[b.D - 1], hid, pt, h, live);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // trunk: d h_{i-1} = W_i[:, hidden]^T d z_i, masked by layer i-1's ReLU
+        for (int i = b.D - 1; i >= 1; --i) {
+            zero_tiles<8>(acc);
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) chunk_ktile8(pipe, cur, acc, hid[kt]);
+            mask_tiles<8>(hid, acc, b.fwd.h[i - 1], b.fwd.h_ld[i - 1], pt, h);
+            store_tiles<8>(b.out.h[i - 1], b.out.h_ld[i - 1], hid, pt, h, live);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+hipError_t launch_mlp_bwd(const MlpBwdLaunch& b, hipStream_t s) {
+    if (b.n_points <= 0) return hipSuccess;
+    if (b.n_chunks != 12 + 8 * (b.D - 1) || b.C < 4) return hipErrorInvalidValue;
+    if (b.n_points > (int64_t)1 << 22) return hipErrorInvalidValue;      // 32-bit element offsets in load/store_tiles
+    const int64_t tiles = (b.n_points + kPointsPerGroup - 1) / kPointsPerGroup;
+    static int n_cu[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!n_cu[dev]) {
+        e = hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        if (n_cu[dev] <= 0) n_cu[dev] = 256;
+    }
+    const dim3 grid((unsigned)(tiles < n_cu[dev] ? tiles : n_cu[dev])), block(256);
+    const size_t lds = kBiasLdsBytes + kRing * kChunkBytes;
+    static bool raised[64] = {};
+    if (!raised[dev]) {
+        e = hipFuncSetAttribute((const void*)nerf_mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised[dev] = true;
+    }
+    hipLaunchKernelGGL(nerf_mlp_bwd_kernel, grid, block, lds, s, b);
+    return hipGetLastError();
+}
+
 hipError_t launch_mlp(const MlpLaunch& a, int mode, hipStream_t s) {
     if (a.n_points <= 0) return hipSuccess;
     const int64_t tiles = (a.n_points + kPointsPerGroup - 1) / kPointsPerGroup;
@@ -380,7 +551,7 @@ hipError_t launch_mlp(const MlpLaunch& a, int mode, hipStream_t s) {
     const size_t lds = kBiasLdsBytes + kRing * kChunkBytes;
     static bool raised[64][4] = {};
     if (mode < 0 || mode > 2) return hipErrorInvalidValue;
-    if (a.store && mode != kInputRays) return hipErrorInvalidValue;      // the training forward feeds ray records
+    if (a.store && (mode != kInputRays || a.n_points > (int64_t)1 << 22)) return hipErrorInvalidValue;   // training forward: ray records; 32-bit element offsets in store_tiles
     typedef void (*kernel_t)(const MlpLaunch);
     static const kernel_t table[4] = {nerf_mlp_kernel<kInputEmbedded>, nerf_mlp_kernel<kInputPoints>,
                                       nerf_mlp_kernel<kInputRays>, nerf_mlp_kernel<kInputRays, true>};

@@ -58,6 +58,9 @@ struct TrainState {
     float* d_wt = nullptr;       // every weight transposed ([in,out]) at the same w_off: B operand of the forward GEMMs
     int* d_stream_table = nullptr;   // fused-stream element -> index into params (or -1)
     int* d_bias_table = nullptr;
+    int* d_bwd_table = nullptr;      // backward-stream element -> index into params (or -1)
+    float* d_stream_bwd = nullptr;   // transposed-weight stream of the fused backward-data kernel
+    int n_chunks_bwd = 0;
     bool grads_valid = false;
 };
 
@@ -68,6 +71,7 @@ struct PackedNet {
     size_t n_params = 0;
     std::vector<LinearDesc> linears;   // pts_linears[0..D-1], views, then feature, alpha, rgb | output
     std::vector<int> stream_table, bias_table;
+    std::vector<int> bwd_table;        // empty when the fused backward-data kernel does not cover the architecture
     TrainState train;
     float* d_stream = nullptr;   // n_chunks * kChunkFloats
     float* d_bias = nullptr;     // n_bias_tiles * kBiasTileFloats
@@ -130,10 +134,28 @@ struct MlpLaunch {
     MlpStore st;
 };
 
+// Fused backward-data pass (nerf_mlp_bwd_kernel): from d raw to the gradient at every pre-activation, one launch.
+struct MlpBwdLaunch {
+    const float* stream;     // pack_backward_stream
+    int n_chunks;
+    const float* bias;       // the forward bias block (carries the rgb / alpha rows per accumulator register)
+    int n_bias_tiles;
+    int D;
+    int64_t n_points;
+    const float* d_raw;      // [P, C]: d rgb (0..2), d sigma (3)
+    int C;
+    MlpStore fwd;            // the activations the forward pass kept (ReLU masks): h[i], hv
+    MlpStore out;            // h[i] = d(pre-activation of trunk layer i), feat = d feature, hv = d(view pre-activation)
+};
+
 // host-side packer (pack_weights.cpp)
 int pack_weights(const nerf_arch& arch, const float* const* tensors, int n_tensors,
                  float** stream_out, int* n_chunks, float** bias_out, int* n_bias_tiles,
                  uint32_t* skip_in_mask, int* out_ch);
+
+// stream of the fused backward-data kernel (view-dependent networks; see pack_weights.cpp)
+int pack_backward_stream(const nerf_arch& arch, const float* const* tensors, uint32_t skip_in_mask, float** stream_out,
+                         int* n_chunks);
 
 // scale group ("layer") of every chunk of the stream, in stream order
 std::vector<int> chunk_layers(const nerf_arch& arch, uint32_t skip_in_mask);
@@ -141,6 +163,7 @@ std::vector<int> chunk_layers(const nerf_arch& arch, uint32_t skip_in_mask);
 // kernel launchers (mlp_kernel.hip, mlp_kernel_h2.hip, ray_kernels.hip)
 hipError_t launch_mlp(const MlpLaunch& a, int mode, hipStream_t s);
 hipError_t launch_mlp_h2(const MlpLaunch& a, int mode, hipStream_t s);
+hipError_t launch_mlp_bwd(const MlpBwdLaunch& b, hipStream_t s);
 // the Linear whose outputs are re-quantised after layer l (trunk 0..D-1, then feature_linear), for launch_layer_gains
 struct GainRefs {
     int n;

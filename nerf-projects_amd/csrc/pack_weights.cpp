@@ -44,8 +44,15 @@ struct Linear {
 // group g of a chunk: 64 lanes x 4 consecutive k-steps: lane = (row lane & 31, half h = lane >> 5), group t4 of a unit
 // holds k-steps 4 t4 .. 4 t4 + 3 -> col(t, h).
 
-template <class ColFn>
-void fill_group(float* chunk, int g, const Linear& L, int ot, int t4, ColFn col) {
+// the transpose of the hidden part of a Linear, as the backward-data pass contracts it: d in[r] = sum_c W[c][col0 + r] * d out[c]
+struct LinearT {
+    const float* w;   // the Linear's [out, ld] row-major weight
+    int rows, k, ld, col0;
+    float at(int r, int c) const { return (r < rows && c >= 0 && c < k) ? w[(size_t)c * ld + col0 + r] : 0.0f; }
+};
+
+template <class Lin, class ColFn>
+void fill_group(float* chunk, int g, const Lin& L, int ot, int t4, ColFn col) {
     float* dst = chunk + (size_t)g * kGroupFloats;
     for (int lane = 0; lane < 64; ++lane) {
         const int row = 32 * ot + (lane & 31), h = lane >> 5;
@@ -54,8 +61,8 @@ void fill_group(float* chunk, int g, const Linear& L, int ot, int t4, ColFn col)
 }
 
 // one k-tile x `n_ot` (<= 8) output tiles: group = ot*4 + t4
-template <class ColFn>
-void chunk_ktile(Stream& s, const Linear& L, int n_ot, ColFn col) {
+template <class Lin, class ColFn>
+void chunk_ktile(Stream& s, const Lin& L, int n_ot, ColFn col) {
     float* c = s.new_chunk();
     for (int ot = 0; ot < n_ot; ++ot)
         for (int t4 = 0; t4 < 4; ++t4) fill_group(c, ot * 4 + t4, L, ot, t4, col);
@@ -98,6 +105,40 @@ std::vector<int> chunk_layers(const nerf_arch& a, uint32_t mask) {
         ids.insert(ids.end(), 1, a.D);
     }
     return ids;
+}
+
+// The weight stream of the fused backward-data kernel (mlp_kernel.hip, nerf_mlp_bwd_kernel; view-dependent networks):
+// the same fragment format as the forward stream, every chunk one k-tile against 8 output tiles, for the chain
+//   d feature = W_views[:, :W]^T d(view pre-activation)     4 chunks  (k = the W/2 view units)
+//   d h_{D-1} = W_feature^T d feature                        8 chunks
+//   d h_{i-1} = W_i[:, hidden columns]^T d z_i, i = D-1..1   8 chunks each
+// `tensors` in state_dict order as for pack_weights; validated there.
+int pack_backward_stream(const nerf_arch& a, const float* const* tensors, uint32_t mask, float** stream_out,
+                         int* n_chunks) {
+    if (!a.use_viewdirs || a.W != kWidth) {
+        set_error("pack_backward_stream: view-dependent networks of width %d only", kWidth);
+        return NERF_E_INVALID;
+    }
+    Stream st;
+    auto layer = [&](const LinearT& T, int n_kt) {
+        for (int kt = 0; kt < n_kt; ++kt) chunk_ktile(st, T, 8, [kt](int t, int h) { return hid_col(kt, t, h); });
+    };
+    const float* const* head = tensors + 2 * a.D + 2;
+    layer(LinearT{tensors[2 * a.D], a.W, a.W / 2, a.W + a.input_ch_views, 0}, 4);
+    layer(LinearT{head[0], a.W, a.W, a.W, 0}, 8);
+    for (int i = a.D - 1; i >= 1; --i) {
+        const bool pe_in = (mask >> i) & 1;
+        layer(LinearT{tensors[2 * i], a.W, a.W, pe_in ? a.W + a.input_ch : a.W, pe_in ? a.input_ch : 0}, 8);
+    }
+    float* out = (float*)malloc(st.data.size() * sizeof(float));
+    if (!out) {
+        set_error("out of host memory packing weights");
+        return NERF_E_NOMEM;
+    }
+    memcpy(out, st.data.data(), st.data.size() * sizeof(float));
+    *stream_out = out;
+    *n_chunks = (int)(st.data.size() / kChunkFloats);
+    return NERF_OK;
 }
 
 int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors, float** stream_out,

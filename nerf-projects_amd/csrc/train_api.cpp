@@ -31,6 +31,12 @@ int ensure_train_state(nerf_ctx* c, PackedNet& net) {
                       hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t.d_bias_table, net.bias_table.data(), net.bias_table.size() * sizeof(int),
                       hipMemcpyHostToDevice));
+    if (!net.bwd_table.empty()) {
+        HIP_TRY(hipMalloc((void**)&t.d_bwd_table, net.bwd_table.size() * sizeof(int)));
+        HIP_TRY(hipMemcpy(t.d_bwd_table, net.bwd_table.data(), net.bwd_table.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&t.d_stream_bwd, net.bwd_table.size() * sizeof(float)));
+        t.n_chunks_bwd = (int)(net.bwd_table.size() / kChunkFloats);
+    }
     t.ready = true;
     return NERF_OK;
 }
@@ -44,6 +50,8 @@ int refresh_derived(PackedNet& net, hipStream_t s) {
     HIP_TRY(launch_convert_stream_h2(net.d_stream, net.d_chunk_layer, net.n_chunks, net.d_chunk_max, net.d_stream_h2,
                                      net.d_descale, s));
     HIP_TRY(launch_layer_gains(net.d_params, gain_refs(net.arch, net.linears), net.d_gain, s));
+    if (net.train.d_stream_bwd)
+        HIP_TRY(launch_gather(net.d_params, net.train.d_bwd_table, (int64_t)net.bwd_table.size(), net.train.d_stream_bwd, s));
     return NERF_OK;
 }
 
@@ -57,12 +65,15 @@ struct Pass {              // one network evaluated at P = N*S points with every
     std::vector<int> h_ld;
     float *vcat = nullptr, *hv = nullptr, *raw = nullptr, *d_raw = nullptr;
     float *g_a = nullptr, *g_b = nullptr, *g_hv = nullptr;   // gradient scratch
+    std::vector<float*> dz;      // fused backward: d(pre-activation) of trunk layer i, [P, W]
+    bool fused_backward = false;
     int vcat_ld = 0, C = 4;
 };
 
 size_t pass_floats(const PackedNet& net, int64_t P) {
     const nerf_arch& a = net.arch;
     size_t f = (size_t)P * a.input_ch;
+    f += (size_t)a.D * ((size_t)P * a.W + 64);      // Pass::dz (fused backward)
     for (int i = 0; i < a.D; ++i) f += (size_t)P * (a.W + a.input_ch);
     f += (size_t)P * (a.W + a.input_ch_views) + (size_t)P * (a.W / 2);
     f += (size_t)P * 8 * 2;                     // raw, d_raw (<= 8 channels budgeted... out_ch <= 32 handled below)
@@ -110,6 +121,9 @@ void carve_pass(Arena& ar, Pass& ps) {
     ps.g_a = ar.take((size_t)P * a.W);
     ps.g_b = ar.take((size_t)P * a.W);
     ps.g_hv = ar.take((size_t)P * (a.W / 2));
+    ps.dz.assign(a.D, nullptr);
+    if (ps.fused_backward)
+        for (int i = 0; i < a.D; ++i) ps.dz[i] = ar.take((size_t)P * a.W);     // d(pre-activation) of every trunk layer
 }
 
 // The training forward pass. NERF_TRAIN_GEMM_FORWARD=1 in the environment (or a network the fused kernel's store
@@ -237,7 +251,61 @@ int grad_linear(const PackedNet& net, const LinearDesc& d, const float* dY, int 
     return NERF_OK;
 }
 
+// The backward pass with the data gradients from ONE launch of nerf_mlp_bwd_kernel (mlp_kernel.hip): d raw -> the
+// gradient at every pre-activation, transposed weights streamed, the running gradient chained in registers, masks read
+// from the activations the forward pass kept. The weight gradients stay what they were: one gemm_tn per Linear
+// (dW = dZ^T X, slices summed in a fixed order), now all issued after that launch. NERF_TRAIN_GEMM_BACKWARD=1 keeps the
+// layer-by-layer chain below (also used for networks without view directions).
+bool gemm_backward_requested() {
+    static const bool on = [] {
+        const char* e = getenv("NERF_TRAIN_GEMM_BACKWARD");
+        return e && *e && *e != '0';
+    }();
+    return on;
+}
+
+int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
+    const PackedNet& net = *ps.net;
+    const nerf_arch& a = net.arch;
+    const LinearDesc &views = net.linears[a.D], &feat = net.linears[a.D + 1], &alpha = net.linears[a.D + 2],
+                     &rgb = net.linears[a.D + 3];
+    float* d_feat = ps.g_a;      // [P, W]
+    MlpBwdLaunch b{};
+    b.stream = net.train.d_stream_bwd;
+    b.n_chunks = net.train.n_chunks_bwd;
+    b.bias = net.d_bias;
+    b.n_bias_tiles = net.n_bias_tiles;
+    b.D = a.D;
+    b.n_points = ps.P;
+    b.d_raw = ps.d_raw;
+    b.C = ps.C;
+    for (int i = 0; i < a.D; ++i) {
+        b.fwd.h[i] = ps.h[i];
+        b.fwd.h_ld[i] = ps.h_ld[i];
+        b.out.h[i] = ps.dz[i];
+        b.out.h_ld[i] = a.W;
+    }
+    b.fwd.hv = ps.hv;
+    b.fwd.hv_ld = views.out;
+    b.out.hv = ps.g_hv;
+    b.out.hv_ld = views.out;
+    b.out.feat = d_feat;
+    b.out.feat_ld = a.W;
+    HIP_TRY(launch_mlp_bwd(b, s));
+    const float* hl = ps.h[a.D - 1];
+    const int hl_ld = ps.h_ld[a.D - 1];
+    int rc;
+    if ((rc = grad_linear(net, rgb, ps.d_raw, ps.C, ps.hv, views.out, ps.P, sc, s))) return rc;
+    if ((rc = grad_linear(net, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, ps.P, sc, s))) return rc;
+    if ((rc = grad_linear(net, feat, d_feat, a.W, hl, hl_ld, ps.P, sc, s))) return rc;
+    if ((rc = grad_linear(net, alpha, ps.d_raw + 3, ps.C, hl, hl_ld, ps.P, sc, s))) return rc;
+    for (int i = a.D - 1; i >= 0; --i)
+        if ((rc = grad_linear(net, net.linears[i], ps.dz[i], a.W, ps.in[i], ps.in_ld[i], ps.P, sc, s))) return rc;
+    return NERF_OK;
+}
+
 int backward_pass(Pass& ps, const TnScratch& sc, hipStream_t s) {
+    if (ps.fused_backward) return backward_pass_fused(ps, sc, s);
     const PackedNet& net = *ps.net;
     const nerf_arch& a = net.arch;
     const float* prm = net.d_params;
@@ -381,6 +449,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     pc.N = N;
     pc.P = Pc;
     pc.S = Sc;
+    pc.fused_backward = !gemm_backward_requested() && nc.train.d_stream_bwd != nullptr && nc.out_ch == 4;
     carve_pass(ar, pc);
     Pass pf;
     if (Si) {
@@ -388,6 +457,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
         pf.N = N;
         pf.P = Pf;
         pf.S = Sf;
+        pf.fused_backward = !gemm_backward_requested() && nf.train.d_stream_bwd != nullptr && nf.out_ch == 4;
         carve_pass(ar, pf);
     }
 
