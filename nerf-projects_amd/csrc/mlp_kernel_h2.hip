@@ -602,19 +602,23 @@ __global__ __launch_bounds__(256) void convert_stream_h2_kernel(const float* str
 }
 
 // gain[2l] = max over output rows of sum_k |W[row][k]|, gain[2l+1] = max |bias|, for the layers whose outputs
-// are re-quantised (see Pending)
+// are re-quantised (see Pending). Grid (layer, row group of 64): four threads share a row; the per-layer maxima are
+// combined with integer atomicMax on the bit patterns (non-negative floats order like their bits; a maximum does not
+// depend on the order of its operands, so the result is deterministic). `gain` is zeroed by the launcher.
 __global__ __launch_bounds__(256) void layer_gain_kernel(const float* params, const GainRefs refs, float* gain) {
     __shared__ float red[2][4];
     const int l = blockIdx.x;
-    const float* w = params + refs.w_off[l];
-    const float* b = params + refs.b_off[l];
-    float g = 0.0f, bm = 0.0f;
-    for (int r = threadIdx.x; r < refs.out[l]; r += 256) {
-        float s = 0.0f;
-        for (int k = 0; k < refs.in[l]; ++k) s += fabsf(w[(size_t)r * refs.in[l] + k]);
-        g = fmaxf(g, s);
-        bm = fmaxf(bm, fabsf(b[r]));
+    const int row = blockIdx.y * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3;
+    const int n_in = refs.in[l];
+    float s = 0.0f, bm = 0.0f;
+    if (row < refs.out[l]) {
+        const float* w = params + refs.w_off[l] + (size_t)row * n_in;
+        for (int k = part; k < n_in; k += 4) s += fabsf(w[k]);
+        if (part == 0) bm = fabsf(params[refs.b_off[l] + row]);
     }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    float g = s;
     for (int o = 32; o > 0; o >>= 1) {
         g = fmaxf(g, __shfl_xor(g, o));
         bm = fmaxf(bm, __shfl_xor(bm, o));
@@ -625,14 +629,20 @@ __global__ __launch_bounds__(256) void layer_gain_kernel(const float* params, co
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        gain[2 * l] = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-        gain[2 * l + 1] = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+        const float gm = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        const float bb = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+        atomicMax((int*)&gain[2 * l], __float_as_int(gm));
+        atomicMax((int*)&gain[2 * l + 1], __float_as_int(bb));
     }
 }
 
 hipError_t launch_layer_gains(const float* params, const GainRefs& refs, float* gain, hipStream_t s) {
     if (refs.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(layer_gain_kernel, dim3(refs.n), dim3(256), 0, s, params, refs, gain);
+    hipError_t e = hipMemsetAsync(gain, 0, 2 * (size_t)refs.n * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    int max_out = 1;
+    for (int l = 0; l < refs.n; ++l) max_out = refs.out[l] > max_out ? refs.out[l] : max_out;
+    hipLaunchKernelGGL(layer_gain_kernel, dim3(refs.n, (max_out + 63) / 64), dim3(256), 0, s, params, refs, gain);
     return hipGetLastError();
 }
 

@@ -42,9 +42,12 @@ int ensure_train_state(nerf_ctx* c, PackedNet& net) {
 }
 
 // W^T copies for the forward GEMMs and the fused inference stream, from the master parameters
+bool gemm_forward_requested();
+
 int refresh_derived(PackedNet& net, hipStream_t s) {
-    for (const LinearDesc& d : net.linears)
-        HIP_TRY(launch_transpose(net.d_params + d.w_off, d.out, d.in, net.train.d_wt + d.w_off, s));
+    if (gemm_forward_requested())      // W^T is the B operand of the layer-by-layer forward GEMMs only
+        for (const LinearDesc& d : net.linears)
+            HIP_TRY(launch_transpose(net.d_params + d.w_off, d.out, d.in, net.train.d_wt + d.w_off, s));
     HIP_TRY(launch_gather(net.d_params, net.train.d_stream_table, (int64_t)net.stream_table.size(), net.d_stream, s));
     HIP_TRY(launch_gather(net.d_params, net.train.d_bias_table, (int64_t)net.bias_table.size(), net.d_bias, s));
     HIP_TRY(launch_convert_stream_h2(net.d_stream, net.d_chunk_layer, net.n_chunks, net.d_chunk_max, net.d_stream_h2,

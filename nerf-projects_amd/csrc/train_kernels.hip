@@ -234,74 +234,85 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmTN g) {
 
     const int bn = ptid & 127, bp0 = (ptid >> 7) * 16;   // B staging: thread = (column, half of the 32 points)
     float colsum = 0.0f;                        // loaders: sum over this slice's points of A[:, ptid]
-    auto stage = [&](int t, int buf) {
-        const int64_t p0 = p_begin + (int64_t)t * 32;
-        float* as = As + buf * 256 * kLd;
-        float* bs = Bs + buf * 128 * kLd;
-        float ra[32], rb[16];
-#pragma unroll
-        for (int it = 0; it < 32; ++it) {
-            const int64_t p = p0 + it;
-            ra[it] = (p < p_end && ptid < g.Mo) ? g.A[p * g.lda + ptid] : 0.0f;
-        }
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int64_t p = p0 + bp0 + it;
-            const int n = n0 + bn;
-            rb[it] = (p < p_end && n < g.No) ? g.B[p * g.ldb + n] : 0.0f;
-        }
-#pragma unroll
-        for (int it = 0; it < 32; ++it) colsum += ra[it];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            f32x4 v = {ra[4 * q], ra[4 * q + 1], ra[4 * q + 2], ra[4 * q + 3]};
-            *(f32x4*)&as[ptid * kLd + 4 * q] = v;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 v = {rb[4 * q], rb[4 * q + 1], rb[4 * q + 2], rb[4 * q + 3]};
-            *(f32x4*)&bs[bn * kLd + bp0 + 4 * q] = v;
-        }
-    };
 
-    f32x16 acc[2][4];
-    if (consumer) {
+    // Like gemm_rows, the two roles run separate loops with the same barrier count. A loader requests point-tile t + 2
+    // right after it has written tile t + 1 to LDS, so a tile's global loads have a whole consumer period (128 MFMAs)
+    // to arrive before they are needed instead of sitting, with the LDS writes behind them, inside one period.
+    if (!consumer) {
+        float ra[32], rb[16];
+        auto request = [&](int t) {
+            const int64_t p0 = p_begin + (int64_t)t * 32;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
-    } else if (n_pt > 0) {
-        stage(0, 0);
-    }
-    __syncthreads();
-    for (int t = 0; t < n_pt; ++t) {
-        if (consumer) {
-            const float* as = As + (t & 1) * 256 * kLd;
-            const float* bs = Bs + (t & 1) * 128 * kLd;
-            const F16 a0 = frag_at(as, 32 * mt0 + j, h), a1 = frag_at(as, 32 * mt1 + j, h);
-            F16 cur = frag_at(bs, j, h);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                mma_frag<0, 1>(acc[0][c], a0, cur);
-                FENCE();
-                F16 nxt = cur;
-                if (c + 1 < 4) nxt = frag_at(bs, 32 * (c + 1) + j, h);
-                FENCE();
-                mma_frag<1, 16>(acc[0][c], a0, cur);
-                mma_frag<0, 16>(acc[1][c], a1, cur);
-                FENCE();
-                cur = nxt;
+            for (int it = 0; it < 32; ++it) {
+                const int64_t p = p0 + it;
+                ra[it] = (p < p_end && ptid < g.Mo) ? g.A[p * g.lda + ptid] : 0.0f;
             }
-        } else if (t + 1 < n_pt) {
-            stage(t + 1, (t + 1) & 1);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int64_t p = p0 + bp0 + it;
+                const int n = n0 + bn;
+                rb[it] = (p < p_end && n < g.No) ? g.B[p * g.ldb + n] : 0.0f;
+            }
+        };
+        auto deposit = [&](int buf) {
+            float* as = As + buf * 256 * kLd;
+            float* bs = Bs + buf * 128 * kLd;
+#pragma unroll
+            for (int it = 0; it < 32; ++it) colsum += ra[it];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                f32x4 v = {ra[4 * q], ra[4 * q + 1], ra[4 * q + 2], ra[4 * q + 3]};
+                *(f32x4*)&as[ptid * kLd + 4 * q] = v;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {rb[4 * q], rb[4 * q + 1], rb[4 * q + 2], rb[4 * q + 3]};
+                *(f32x4*)&bs[bn * kLd + bp0 + 4 * q] = v;
+            }
+        };
+        if (n_pt > 0) {
+            request(0);
+            deposit(0);
+            if (n_pt > 1) request(1);
         }
         __syncthreads();
-    }
-    if (!consumer) {
+        for (int t = 0; t < n_pt; ++t) {
+            if (t + 1 < n_pt) {
+                deposit((t + 1) & 1);
+                if (t + 2 < n_pt) request(t + 2);
+            }
+            __syncthreads();
+        }
         if (g.dbp && blockIdx.y == 0 && ptid < g.Mo) g.dbp[(int64_t)slice * g.Mo + ptid] = colsum;
         return;
+    }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
+    __syncthreads();
+    for (int t = 0; t < n_pt; ++t) {
+        const float* as = As + (t & 1) * 256 * kLd;
+        const float* bs = Bs + (t & 1) * 128 * kLd;
+        const F16 a0 = frag_at(as, 32 * mt0 + j, h), a1 = frag_at(as, 32 * mt1 + j, h);
+        F16 cur = frag_at(bs, j, h);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            mma_frag<0, 1>(acc[0][c], a0, cur);
+            FENCE();
+            F16 nxt = cur;
+            if (c + 1 < 4) nxt = frag_at(bs, 32 * (c + 1) + j, h);
+            FENCE();
+            mma_frag<1, 16>(acc[0][c], a0, cur);
+            mma_frag<0, 16>(acc[1][c], a1, cur);
+            FENCE();
+            cur = nxt;
+        }
+        __syncthreads();
     }
     float* part = g.part + (int64_t)slice * g.Mo * no_eff;
 #pragma unroll
@@ -328,8 +339,18 @@ __global__ void reduce_slices_kernel(const float* __restrict__ part, const float
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n_w = (int64_t)Mo * No;
     if (idx < n_w) {
+        // the slices are added in order (deterministic); eight loads are in flight at a time - with one dependent load per
+        // iteration the 33 MB of a layer's partials streamed at a quarter of what the memory system gives
         float s = 0.0f;
-        for (int k = 0; k < n_slices; ++k) s += part[(int64_t)k * n_w + idx];
+        int k = 0;
+        for (; k + 8 <= n_slices; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(k + u) * n_w + idx];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < n_slices; ++k) s += part[(int64_t)k * n_w + idx];
         float* w = dW + (idx / No) * ldw + (idx % No);
         *w = accumulate ? *w + s : s;   // second pass through a shared network: .grad accumulates (nerf.ipynb:1270)
     } else if (idx < n_w + Mo && db && dbp) {
