@@ -44,8 +44,14 @@ def gather_frame(local, n_total, group=None, dst=0, force_collective=False):
         parts = [buf]
     else:
         dst_global = dist.get_global_rank(group, dst) if group is not None else dst
-        parts = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-        dist.gather(buf, parts, dst=dst_global, group=group)
+        # RCCL (backend "nccl") gathers device buffers; gloo - used to rehearse the N > 1 path where the ranks cannot
+        # each have a GPU of their own - only moves host memory, so the packed buffer takes a detour through the host
+        via_host = buf.is_cuda and dist.get_backend(group) == "gloo"
+        send = buf.cpu() if via_host else buf
+        parts = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+        dist.gather(send, parts, dst=dst_global, group=group)
+        if via_host and parts is not None:
+            parts = [p.to(dev) for p in parts]
     if rank != dst:
         return None
     out = {}

@@ -639,6 +639,29 @@ def test_nonfinite_inputs_propagate_like_the_reference(N, O, nets):
     assert np.isfinite(cpu(ret["acc0"])[17]) and abs(cpu(ret["acc0"])[17] - want["acc0"][17]) <= 1e-5
 
 
+def test_c1_full_frame_coarse_only(N, O, nets):
+    """BASELINE configs[1] at full size: lego 400x400, 64 coarse samples, coarse network only (160 000 rays through
+    render()). Without resampling the output is well conditioned: every one of 2 000 rays spread over the frame is
+    within 1e-5 of the oracle (north_star's 1e-4 bar met outright), and the frame is chunk-independent to the bit."""
+    net_c, _, q = nets
+    H = W = 400
+    K, c2w, near, far = synthetic.lego_camera(H, W)
+    kw = dict(network_fn=net_c, network_query_fn=q, N_samples=64, N_importance=0, network_fine=None, white_bkgd=True,
+              perturb=0., raw_noise_std=0.)
+    cam = dict(c2w=c2w, ndc=False, near=near, far=far, use_viewdirs=True)
+    rgb, disp, acc, extras = N.render(H, W, K, chunk=32768, **cam, **kw)
+    assert rgb.shape == (H, W, 3) and extras == {} and torch.isfinite(rgb).all()
+    rgb2 = N.render(H, W, K, chunk=10000, **cam, **kw)[0]
+    assert torch.equal(rgb, rgb2)
+    idx = np.linspace(0, H * W - 1, 2000).astype(np.int64)
+    packed, _ = O.pack_rays(H, W, K, c2w=c2w, ndc=False, near=near, far=far, use_viewdirs=True)
+    oq = O.make_query_fn(O.get_embedder(10)[0], O.get_embedder(4)[0])
+    want = O.render_rays(packed[idx], O.NeRF(8, 256, 63, 27, 4, (4,), True, net_c._sd), oq, N_samples=64, white_bkgd=True)
+    assert np.abs(cpu(rgb).reshape(-1, 3)[idx] - want["rgb_map"]).max() <= 1e-5
+    assert np.abs(cpu(acc).reshape(-1)[idx] - want["acc_map"]).max() <= 1e-5
+    _disp_close(cpu(disp).reshape(-1)[idx], want["disp_map"], want["acc_map"])
+
+
 # ---- error behaviour -------------------------------------------------------------------------
 
 def test_errors_are_exceptions(N, nets):
