@@ -118,8 +118,15 @@ struct Range {
 //
 // The barrier follows step NSTEP/2-1 (see Pipe); the 8 LDS-DMA issues of chunk c+2 come right
 // after it.
-template <int S, int NSTEP, class Body>
-__device__ __forceinline__ void run_steps(Pipe& p, Frag16& cur, const f32x4* fr, const f32x4* fr_next, Body& body) {
+struct NoPost {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `post()` runs once per chunk, at the end of the step that follows the mid-chunk barrier: the training kernels issue a
+// tile's global stores there, a whole barrier period (7 of 8 steps) before the next barrier's vmcnt(0) asks for their
+// acknowledgement. Issued in one burst at a layer boundary, 32 stores per lane were still in flight at the next barrier.
+template <int S, int NSTEP, class Body, class Post>
+__device__ __forceinline__ void run_steps(Pipe& p, Frag16& cur, const f32x4* fr, const f32x4* fr_next, Body& body,
+                                          Post& post) {
     if constexpr (S < NSTEP) {
         // order pinned with scheduling fences: the step's first MFMA, the four fragment reads of step S+1 into the
         // other half of a double buffer, then the other 15 MFMAs (960 matrix-pipe cycles for the reads to return).
@@ -139,6 +146,8 @@ __device__ __forceinline__ void run_steps(Pipe& p, Frag16& cur, const f32x4* fr,
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            post();
         } else {
             body(StepTag<S>{}, Range<1, 16>{}, cur);
         }
@@ -150,25 +159,26 @@ __device__ __forceinline__ void run_steps(Pipe& p, Frag16& cur, const f32x4* fr,
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
-        run_steps<S + 1, NSTEP>(p, cur, fr, fr_next, body);
+        run_steps<S + 1, NSTEP>(p, cur, fr, fr_next, body, post);
     }
 }
 
-template <int NSTEP, class Body>
-__device__ __forceinline__ void consume_chunk(Pipe& p, Frag16& cur, Body body) {
+template <int NSTEP, class Body, class Post = NoPost>
+__device__ __forceinline__ void consume_chunk(Pipe& p, Frag16& cur, Body body, Post post = Post{}) {
     const f32x4* fr = ring_frags(p, p.b);
     const f32x4* fr_next = ring_frags(p, ring_next(p.b, 1));
-    run_steps<0, NSTEP>(p, cur, fr, fr_next, body);
+    run_steps<0, NSTEP>(p, cur, fr, fr_next, body, post);
     ++p.c;
     p.b = ring_next(p.b, 1);
 }
 
 // chunk kinds (group orders fixed by pack_weights.cpp) -------------------------------------------
 // one k-tile against 8 output tiles: step s = output tile s
-__device__ __forceinline__ void chunk_ktile8(Pipe& p, Frag16& cur, f32x16 (&acc)[8], const f32x16& b) {
+template <class Post = NoPost>
+__device__ __forceinline__ void chunk_ktile8(Pipe& p, Frag16& cur, f32x16 (&acc)[8], const f32x16& b, Post post = Post{}) {
     consume_chunk<8>(p, cur, [&](auto tag, auto rng, const Frag16& f) {
         mma_range<decltype(rng)::lo, decltype(rng)::hi>(acc[decltype(tag)::value], f, b);
-    });
+    }, post);
 }
 // one k-tile against 4 output tiles (direction part of the view layer)
 __device__ __forceinline__ void chunk_ktile4(Pipe& p, Frag16& cur, f32x16 (&acc)[8], const f32x16& b) {
@@ -177,12 +187,13 @@ __device__ __forceinline__ void chunk_ktile4(Pipe& p, Frag16& cur, f32x16 (&acc)
     });
 }
 // two k-tiles against 4 output tiles (feature part of the view layer): steps 0-3 use b0, 4-7 use b1
+template <class Post = NoPost>
 __device__ __forceinline__ void chunk_pair4(Pipe& p, Frag16& cur, f32x16 (&acc)[8], const f32x16& b0,
-                                            const f32x16& b1) {
+                                            const f32x16& b1, Post post = Post{}) {
     consume_chunk<8>(p, cur, [&](auto tag, auto rng, const Frag16& f) {
         constexpr int s = decltype(tag)::value;
         mma_range<decltype(rng)::lo, decltype(rng)::hi>(acc[s & 3], f, s < 4 ? b0 : b1);
-    });
+    }, post);
 }
 // NKT k-tiles against ONE output tile: step s = k-tile s
 template <int NKT>
@@ -258,6 +269,25 @@ __device__ __forceinline__ void store_tiles(float* base, int ld, const f32x16 (&
         }
 }
 
+// one tile (feature columns 32 i .. 32 i + 31) of the same
+__device__ __forceinline__ void store_tile(float* base, int ld, const f32x16& t, int i, int64_t pt, int h, bool live) {
+    if (base == nullptr || !live) return;
+    float* row = base + (uint32_t)((uint32_t)pt * (uint32_t)ld + 4u * (uint32_t)h) + 32 * i;
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float* p = row + 8 * q;
+        if (vec) {
+            *(f32x4*)p = f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+        } else {
+            p[0] = t[4 * q];
+            p[1] = t[4 * q + 1];
+            p[2] = t[4 * q + 2];
+            p[3] = t[4 * q + 3];
+        }
+    }
+}
+
 // ---- the kernel -------------------------------------------------------------------------
 template <int MODE, bool STORE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -296,7 +326,6 @@ void nerf_mlp_kernel(const MlpLaunch a) {
     chunk_ktile8(pipe, cur, acc, x0);
     chunk_ktile8(pipe, cur, acc, x1);
     activate<8, true>(hid, acc);
-    if constexpr (STORE) store_tiles<8>(a.st.h[0], a.st.h_ld[0], hid, pt, h, live);
 
     // trunk layers 1..D-1, then (with viewdirs) feature_linear as layer D without ReLU
     const int n_layers = a.use_viewdirs ? a.D + 1 : a.D;
@@ -309,8 +338,16 @@ void nerf_mlp_kernel(const MlpLaunch a) {
             sigma = row_dot<8>(hid, bias_lds, 8 * a.D + 14, h) + bias_lds[(8 * a.D) * 32];
         }
         load_bias<8>(acc, bias_lds, is_feature ? 8 * a.D + 1 : 8 * i, h);
+        // (training: tile kt of the previous layer's output - this chunk's B operand - goes to memory behind this chunk's
+        // barrier)
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) chunk_ktile8(pipe, cur, acc, hid[kt]);
+        for (int kt = 0; kt < 8; ++kt) {
+            if constexpr (STORE)
+                chunk_ktile8(pipe, cur, acc, hid[kt],
+                             [&]() { store_tile(a.st.h[i - 1], a.st.h_ld[i - 1], hid[kt], kt, pt, h, live); });
+            else
+                chunk_ktile8(pipe, cur, acc, hid[kt]);
+        }
         if (!is_feature && ((a.skip_in_mask >> i) & 1)) {
             // h = cat[input_pts, h] (nerf.py:79-80): the encoded inputs are still in registers
             chunk_ktile8(pipe, cur, acc, x0);
@@ -321,12 +358,13 @@ void nerf_mlp_kernel(const MlpLaunch a) {
             // row_dot above and only keeps the ring turning
             consume_chunk<8>(pipe, cur, [&](auto, auto, const Frag16&) {});
             activate<8, false>(hid, acc);
-            if constexpr (STORE) store_tiles<8>(a.st.feat, a.st.feat_ld, hid, pt, h, live);
         } else {
             activate<8, true>(hid, acc);
-            if constexpr (STORE) store_tiles<8>(a.st.h[i], a.st.h_ld[i], hid, pt, h, live);
         }
     }
+    // without a view layer the last trunk output has no following chunks to ride behind
+    if constexpr (STORE)
+        if (!a.use_viewdirs) store_tiles<8>(a.st.h[a.D - 1], a.st.h_ld[a.D - 1], hid, pt, h, live);
 
     unsigned bad;      // NaN / Inf inputs propagate as through F.relu (mlp_inputs.h, kBadXyz): raw inputs re-read here
     {
@@ -337,7 +375,15 @@ void nerf_mlp_kernel(const MlpLaunch a) {
         // views_linears[0] on cat[feature, gamma(dir)] (nerf.py:93-98): 4 output tiles
         load_bias<4>(acc, bias_lds, 8 * a.D + 9, h);
 #pragma unroll
-        for (int kp = 0; kp < 4; ++kp) chunk_pair4(pipe, cur, acc, hid[2 * kp], hid[2 * kp + 1]);
+        for (int kp = 0; kp < 4; ++kp) {
+            if constexpr (STORE)
+                chunk_pair4(pipe, cur, acc, hid[2 * kp], hid[2 * kp + 1], [&]() {
+                    store_tile(a.st.feat, a.st.feat_ld, hid[2 * kp], 2 * kp, pt, h, live);
+                    store_tile(a.st.feat, a.st.feat_ld, hid[2 * kp + 1], 2 * kp + 1, pt, h, live);
+                });
+            else
+                chunk_pair4(pipe, cur, acc, hid[2 * kp], hid[2 * kp + 1]);
+        }
         chunk_ktile4(pipe, cur, acc, dd);
         activate<4, true>(hid, acc);
         if constexpr (STORE) store_tiles<4>(a.st.hv, a.st.hv_ld, hid, pt, h, live);
@@ -466,22 +512,20 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
             for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(d2, w2[r], fmaf(d1, w1[r], d0 * w0[r]));
         }
         mask_tiles<4>(hid, acc, b.fwd.hv, b.fwd.hv_ld, pt, h);
-        store_tiles<4>(b.out.hv, b.out.hv_ld, hid, pt, h, live);
-        __builtin_amdgcn_sched_barrier(0);     // keep the stores (and their addresses) here: spread into the chunk's
-                                               // MFMAs hipcc keeps one spilled 64-bit address per store alive
 
+        // every gradient tile goes to memory behind the barrier of the chunk that contracts over it (see run_steps)
         // d feature = W_views[:, :W]^T d(view pre-activation)
         zero_tiles<8>(acc);
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) chunk_ktile8(pipe, cur, acc, hid[kt]);
+        for (int kt = 0; kt < 4; ++kt)
+            chunk_ktile8(pipe, cur, acc, hid[kt], [&]() { store_tile(b.out.hv, b.out.hv_ld, hid[kt], kt, pt, h, live); });
         activate<8, false>(hid, acc);
-        store_tiles<8>(b.out.feat, b.out.feat_ld, hid, pt, h, live);
-        __builtin_amdgcn_sched_barrier(0);
 
         // d h_{D-1} = W_feature^T d feature + d sigma * w_alpha (alpha row: bias-block tiles 8D+14+t), then its mask
         zero_tiles<8>(acc);
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) chunk_ktile8(pipe, cur, acc, hid[kt]);
+        for (int kt = 0; kt < 8; ++kt)
+            chunk_ktile8(pipe, cur, acc, hid[kt], [&]() { store_tile(b.out.feat, b.out.feat_ld, hid[kt], kt, pt, h, live); });
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const f32x16 wa = *(const f32x16*)(bias_lds + ((8 * b.D + 14 + t) * 2 + h) * 16);
@@ -489,18 +533,16 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
             for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(dsig, wa[r], acc[t][r]);
         }
         mask_tiles<8>(hid, acc, b.fwd.h[b.D - 1], b.fwd.h_ld[b.D - 1], pt, h);
-        store_tiles<8>(b.out.h[b.D - 1], b.out.h_ld[b.D - 1], hid, pt, h, live);
-        __builtin_amdgcn_sched_barrier(0);
 
         // trunk: d h_{i-1} = W_i[:, hidden]^T d z_i, masked by layer i-1's ReLU
         for (int i = b.D - 1; i >= 1; --i) {
             zero_tiles<8>(acc);
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt) chunk_ktile8(pipe, cur, acc, hid[kt]);
+            for (int kt = 0; kt < 8; ++kt)
+                chunk_ktile8(pipe, cur, acc, hid[kt], [&]() { store_tile(b.out.h[i], b.out.h_ld[i], hid[kt], kt, pt, h, live); });
             mask_tiles<8>(hid, acc, b.fwd.h[i - 1], b.fwd.h_ld[i - 1], pt, h);
-            store_tiles<8>(b.out.h[i - 1], b.out.h_ld[i - 1], hid, pt, h, live);
-            __builtin_amdgcn_sched_barrier(0);
         }
+        store_tiles<8>(b.out.h[0], b.out.h_ld[0], hid, pt, h, live);     // d z_0: nothing left to ride behind
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
