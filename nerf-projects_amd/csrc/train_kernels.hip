@@ -53,6 +53,15 @@ __device__ __forceinline__ void mma_frag(f32x16& acc, const F16& a, const F16& b
 // use, i.e. after them, and waits for the first quad at the head of every step.
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// The loaders' barrier: LDS writes visible (lgkmcnt(0)), then s_barrier - and nothing else. __syncthreads() also waits for
+// vmcnt(0), i.e. for the global loads of the NEXT tile that a loader has just requested: with it every k-tile cost its
+// load time PLUS its MFMA time (timing-only ablations of round 2: 31 + 108 + 66 = 205 us per launch, the parts adding up
+// exactly), the prefetch distance notwithstanding. The data registers of those loads are tracked by the compiler as usual:
+// it waits for them where deposit() reads them.
+__device__ __forceinline__ void loader_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------------------------
 // C[M,N] = A[M,K] * B[K,N]      (N <= 256, any K; one workgroup = 128 rows x all N columns)
 //
@@ -79,6 +88,8 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmRows g) {
     // k-tile kt + 1 to LDS: a tile's global loads have a whole consumer period (128 MFMAs) to arrive before they are
     // needed, instead of sitting between two barriers with the conversion to LDS behind them.
     if (!consumer) {
+        // (one register set here: the two-set form of gemm_tn_kernel needs 96 staging registers next to this kernel's 256-
+        // register consumers and spills; this kernel is the fallback path since the fused forward / backward kernels)
         float ra[16], rb[32];
         auto request = [&](int kt) {
             const int k0 = kt * 32;
@@ -109,13 +120,13 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmRows g) {
         request(0);
         deposit(0);
         if (n_kt > 1) request(1);
-        __syncthreads();
+        loader_barrier();
         for (int kt = 0; kt < n_kt; ++kt) {
             if (kt + 1 < n_kt) {
                 deposit((kt + 1) & 1);
                 if (kt + 2 < n_kt) request(kt + 2);
             }
-            __syncthreads();
+            loader_barrier();
         }
         return;
     }
@@ -239,22 +250,33 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmTN g) {
     // right after it has written tile t + 1 to LDS, so a tile's global loads have a whole consumer period (128 MFMAs)
     // to arrive before they are needed instead of sitting, with the LDS writes behind them, inside one period.
     if (!consumer) {
-        float ra[32], rb[16];
-        auto request = [&](int t) {
+        // Two register sets, tile k in set k & 1, and the loop unrolled by two: with ONE set carried around the loop
+        // hipcc copies the freshly loaded registers at the back edge, i.e. waits for the loads it has just issued, and
+        // the prefetch distance is gone (the kernel then costs its load time plus its MFMA time; round-2 ablations).
+        float ra0[32], rb0[16], ra1[32], rb1[16];
+        auto request = [&](int t, float (&ra)[32], float (&rb)[16]) {
             const int64_t p0 = p_begin + (int64_t)t * 32;
 #pragma unroll
             for (int it = 0; it < 32; ++it) {
                 const int64_t p = p0 + it;
+#ifdef NERF_ABLATE_TN_LOADS
+                ra[it] = (float)(p & 7);
+#else
                 ra[it] = (p < p_end && ptid < g.Mo) ? g.A[p * g.lda + ptid] : 0.0f;
+#endif
             }
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const int64_t p = p0 + bp0 + it;
                 const int n = n0 + bn;
+#ifdef NERF_ABLATE_TN_LOADS
+                rb[it] = (float)((p + n) & 7);
+#else
                 rb[it] = (p < p_end && n < g.No) ? g.B[p * g.ldb + n] : 0.0f;
+#endif
             }
         };
-        auto deposit = [&](int buf) {
+        auto deposit = [&](int buf, const float (&ra)[32], const float (&rb)[16]) {
             float* as = As + buf * 256 * kLd;
             float* bs = Bs + buf * 128 * kLd;
 #pragma unroll
@@ -271,17 +293,25 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmTN g) {
             }
         };
         if (n_pt > 0) {
-            request(0);
-            deposit(0);
-            if (n_pt > 1) request(1);
+            request(0, ra0, rb0);
+            deposit(0, ra0, rb0);
+            if (n_pt > 1) request(1, ra1, rb1);
         }
-        __syncthreads();
-        for (int t = 0; t < n_pt; ++t) {
+        loader_barrier();
+        for (int t = 0; t < n_pt; t += 2) {
+            // period t: tile t + 1 (set 1) to buffer 1, tile t + 2 requested into set 0
             if (t + 1 < n_pt) {
-                deposit((t + 1) & 1);
-                if (t + 2 < n_pt) request(t + 2);
+                deposit(1, ra1, rb1);
+                if (t + 2 < n_pt) request(t + 2, ra0, rb0);
             }
-            __syncthreads();
+            loader_barrier();
+            if (t + 1 >= n_pt) break;
+            // period t + 1: tile t + 2 (set 0) to buffer 0, tile t + 3 requested into set 1
+            if (t + 2 < n_pt) {
+                deposit(0, ra0, rb0);
+                if (t + 3 < n_pt) request(t + 3, ra1, rb1);
+            }
+            loader_barrier();
         }
         if (g.dbp && blockIdx.y == 0 && ptid < g.Mo) g.dbp[(int64_t)slice * g.Mo + ptid] = colsum;
         return;
@@ -307,8 +337,10 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmTN g) {
             F16 nxt = cur;
             if (c + 1 < 4) nxt = frag_at(bs, 32 * (c + 1) + j, h);
             FENCE();
+#ifndef NERF_ABLATE_TN_MFMA
             mma_frag<1, 16>(acc[0][c], a0, cur);
             mma_frag<0, 16>(acc[1][c], a1, cur);
+#endif
             FENCE();
             cur = nxt;
         }
