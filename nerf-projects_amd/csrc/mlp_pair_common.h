@@ -175,7 +175,13 @@ __device__ __forceinline__ void run_steps(PipeH& p, Frag4& cur, unsigned fr, uns
         NERF_FENCE();
         cur = nxt;
         if constexpr (S == NSTEP / 2 - 1) {
+#if defined(NERF_ABLATE_BARRIER)      // timing-only builds: what the chunk's synchronisation costs (profiles/r02_kernel_ab.md)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#elif defined(NERF_ABLATE_VMWAIT)
+            asm volatile("s_barrier" ::: "memory");
+#else
             asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+#endif
             NERF_FENCE();
         }
         run_steps<S + 1, NSTEP, NB>(p, cur, fr, fr_next, body);
