@@ -208,9 +208,35 @@ struct GemmTN {        // part[slice][Mo, No] = sum_p A[p,Mo]^T B[p,No];  dbp[sl
     int64_t pts_per_slice;
     float* part;
     float* dbp;
+    int narrow_first;   // the columns beyond a multiple of 256 come first (cat[gamma(x), h]) rather than last
 };
 hipError_t launch_gemm_rows(const GemmRows& g, hipStream_t s);
 hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, float* db, int accumulate, hipStream_t s);
+int gemm_tn_col_blocks(int Mo, int No);
+bool gemm_tn_is_small(int Mo);
+bool gemm_tn_is_direct(int Mo);
+// Several weight gradients in ONE launch (train_dw_kernel.hip): a job = the columns [n_begin, n_end) of one Linear's
+// dW = dY^T X (+ db), Mo a multiple of 128. All jobs of a batch share the point range and its split into slices, so
+// the grid is slices x jobs and a layer needs only 256 / jobs slices to fill the chip: its partials (and the pass that
+// adds them up, in slice order) shrink by the number of jobs.
+struct GradJob {
+    const float* A; int lda;      // dY [P, Mo]
+    const float* B; int ldb;      // X  [P, >= n_end]
+    int Mo, n_begin, n_end;
+    float* dW; int ldw;           // dW[m * ldw + n], n in [n_begin, n_end)
+    float* db;                    // nullptr: this job leaves the bias gradient to another one
+    float* part;                  // [n_slices][Mo][n_end - n_begin]   (set by launch_grad_batch)
+    float* dbp;                   // [n_slices][Mo]
+};
+constexpr int kMaxGradJobs = 12;
+struct GradBatch {
+    int n, n_slices, accumulate;
+    int64_t P, pts_per_slice;
+    GradJob job[kMaxGradJobs];
+};
+// wide: every job is 256 columns (NT = 4); otherwise at most 64 columns each (NT = 1). scratch: part_floats / dbp_floats available
+hipError_t launch_grad_batch(GradBatch& b, bool wide, float* part, size_t part_floats, float* dbp, size_t dbp_floats,
+                             hipStream_t s);
 hipError_t launch_embed_train(const float* rays, int ray_ld, const float* z, int64_t P, int S, int Lx, int Lv,
                               float* xcat, int ldx, float* vcat, int ldv, int voff, hipStream_t s);
 hipError_t launch_mse(const float* x, const float* t, int64_t n, float* grad, double* part, float* loss, hipStream_t s);

@@ -226,16 +226,21 @@ int forward_pass(Pass& ps, const float* rays, int ray_ld, const float* z, hipStr
 
 struct TnScratch {
     float* part;      // [max_slices][256][No <= 320] partial dW
-    float* dbp;       // [max_slices][256] partial db
+    float* dbp;       // [max_slices][256] partial db (twice that: a batch of layers keeps all its bias partials at once)
     int max_slices;
     int64_t P;        // points of the pass being differentiated
     int accumulate;   // add to the gradients already there (the second pass through a shared network)
+    size_t part_floats, dbp_floats;
 };
 
-// Slices per GEMM: the grid is slices x ceil(No/128) workgroups at one per CU, so aim at a whole number of
+// Slices per GEMM: the grid is slices x column blocks (gemm_tn_col_blocks) workgroups at one per CU, so aim at a whole number of
 // 256-workgroup rounds (a 1.5-round grid wastes a third of the machine) while keeping >= 256 points per slice.
-inline int pick_slices(int64_t P, int No, int max_slices) {
-    const int yb = (No + 127) / 128;
+inline int pick_slices(int64_t P, int Mo, int No, int max_slices) {
+    if (gemm_tn_is_small(Mo)) {     // [slices][Mo <= 4][No] partials: 2048 slices fit the buffers sized for 256 x 256 rows
+        const int64_t s = (P + 63) / 64;
+        return (int)(s < 1 ? 1 : (s > 2048 ? 2048 : s));
+    }
+    const int yb = gemm_tn_col_blocks(Mo, No);
     int s = 256 / yb;
     const int64_t cap = (P + 255) / 256;
     if (s > cap) s = (int)cap;
@@ -246,10 +251,13 @@ inline int pick_slices(int64_t P, int No, int max_slices) {
 // dW (+db) of one Linear: dW = dY^T X, db = dY^T 1
 int grad_linear(const PackedNet& net, const LinearDesc& d, const float* dY, int ldy, const float* X, int ldx, int64_t P,
                 const TnScratch& sc, hipStream_t s) {
-    const int n_slices = pick_slices(P, d.in, sc.max_slices);
+    const int n_slices = pick_slices(P, d.out, d.in, sc.max_slices);
     int64_t pps = (P + n_slices - 1) / n_slices;
     pps = (pps + 31) / 32 * 32;
-    GemmTN g{dY, ldy, X, ldx, P, d.out, d.in, pps, sc.part, sc.dbp};
+    // a trunk layer behind a skip reads cat[gamma(x), h] (nerf.py:79-80): its narrow columns come first; the view layer
+    // reads cat[feature, gamma(d)] (nerf.py:93): last
+    const bool trunk = &d >= &net.linears[0] && &d < &net.linears[0] + net.arch.D;
+    GemmTN g{dY, ldy, X, ldx, P, d.out, d.in, pps, sc.part, sc.dbp, (trunk && d.in > net.arch.W) ? 1 : 0};
     HIP_TRY(launch_gemm_tn(g, n_slices, net.train.d_grad + d.w_off, d.in, net.train.d_grad + d.b_off, sc.accumulate, s));
     return NERF_OK;
 }
@@ -299,11 +307,53 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     const int hl_ld = ps.h_ld[a.D - 1];
     int rc;
     if ((rc = grad_linear(net, rgb, ps.d_raw, ps.C, ps.hv, views.out, ps.P, sc, s))) return rc;
-    if ((rc = grad_linear(net, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, ps.P, sc, s))) return rc;
-    if ((rc = grad_linear(net, feat, d_feat, a.W, hl, hl_ld, ps.P, sc, s))) return rc;
     if ((rc = grad_linear(net, alpha, ps.d_raw + 3, ps.C, hl, hl_ld, ps.P, sc, s))) return rc;
-    for (int i = a.D - 1; i >= 0; --i)
-        if ((rc = grad_linear(net, net.linears[i], ps.dz[i], a.W, ps.in[i], ps.in_ld[i], ps.P, sc, s))) return rc;
+    const bool batched = gemm_tn_is_direct(a.W) && gemm_tn_is_direct(views.out) && a.input_ch <= 64 &&
+                         a.input_ch_views <= 64 && a.D + 1 <= kMaxGradJobs;
+    if (!batched) {
+        if ((rc = grad_linear(net, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, ps.P, sc, s))) return rc;
+        if ((rc = grad_linear(net, feat, d_feat, a.W, hl, hl_ld, ps.P, sc, s))) return rc;
+        for (int i = a.D - 1; i >= 0; --i)
+            if ((rc = grad_linear(net, net.linears[i], ps.dz[i], a.W, ps.in[i], ps.in_ld[i], ps.P, sc, s))) return rc;
+        return NERF_OK;
+    }
+    // Every other weight gradient in two launches (+ their reductions): the 256-column blocks of all layers, then the
+    // gamma(x) / gamma(d) columns. With J jobs in a launch a layer is cut into 256 / J slices instead of 256: J times
+    // fewer partial sums to write and to add up (a layer's 256 partials were 67 MB, and the pass over them 12 % of the step).
+    float* grad = net.train.d_grad;
+    GradBatch wide{}, narrow{};
+    auto job = [&](GradBatch& b, const LinearDesc& d, const float* dY, int ldy, const float* X, int ldx, int n0, int n1,
+                   bool with_db) {
+        b.job[b.n++] = GradJob{dY, ldy, X, ldx, d.out, n0, n1, grad + d.w_off, d.in, with_db ? grad + d.b_off : nullptr,
+                               nullptr, nullptr};
+    };
+    job(wide, feat, d_feat, a.W, hl, hl_ld, 0, a.W, true);
+    job(wide, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, 0, a.W, true);          // cat[feature, gamma(d)] (nerf.py:93)
+    if (views.in > a.W) job(narrow, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, a.W, views.in, false);
+    for (int i = a.D - 1; i >= 0; --i) {
+        const LinearDesc& d = net.linears[i];
+        if (d.in >= a.W) {
+            const int lead = d.in - a.W;                                               // cat[gamma(x), h] (nerf.py:79-80)
+            job(wide, d, ps.dz[i], a.W, ps.in[i], ps.in_ld[i], lead, d.in, true);
+            if (lead > 0) job(narrow, d, ps.dz[i], a.W, ps.in[i], ps.in_ld[i], 0, lead, false);
+        } else {
+            job(narrow, d, ps.dz[i], a.W, ps.in[i], ps.in_ld[i], 0, d.in, true);       // layer 0: gamma(x) only
+        }
+    }
+    for (GradBatch* b : {&wide, &narrow}) {
+        if (b->n == 0) continue;
+        int n_slices = 256 / b->n;
+        const int64_t cap = (ps.P + 255) / 256;
+        if (n_slices > cap) n_slices = (int)cap;
+        if (n_slices < 1) n_slices = 1;
+        int64_t pps = (ps.P + n_slices - 1) / n_slices;
+        pps = (pps + 31) / 32 * 32;
+        b->n_slices = n_slices;
+        b->pts_per_slice = pps;
+        b->P = ps.P;
+        b->accumulate = sc.accumulate;
+        HIP_TRY(launch_grad_batch(*b, b == &wide, sc.part, sc.part_floats, sc.dbp, sc.dbp_floats, s));
+    }
     return NERF_OK;
 }
 
@@ -430,7 +480,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     const size_t part_floats = (size_t)n_slices * 256 * (size_t)(nc.arch.W + nc.arch.input_ch + 64);
     const size_t small = (size_t)N * (Sc * 2 + (Si ? Si + Sf * 2 : 0) + 16) + 4096;
     rc = ensure_workspace(c, arena_bytes({small, pass_floats(nc, Pc), Si ? pass_floats(nf, Pf) : 1, part_floats,
-                                          (size_t)n_slices * 256}) +
+                                          (size_t)n_slices * 512}) +
                                  (1 << 20));
     if (rc != NERF_OK) return rc;
     Arena ar(c->ws);
@@ -445,7 +495,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     float* g_f = Si ? ar.take((size_t)N * 3) : nullptr;
     double* red = (double*)ar.take(2048);   // 2 x 512 doubles of per-block partials
     float* loss_dev = ar.take(4);
-    TnScratch sc{ar.take(part_floats), ar.take((size_t)n_slices * 256), n_slices, 0, 0};
+    TnScratch sc{ar.take(part_floats), ar.take((size_t)n_slices * 512), n_slices, 0, 0, part_floats, (size_t)n_slices * 512};
 
     Pass pc;
     pc.net = &nc;

@@ -1,0 +1,220 @@
+// dW = dY^T X of the training step without LDS staging, several layers per launch (declared in nerf_internal.h). Its own translation unit: the 256 accumulators of a wave live in the AGPR half of the register file,
+// so this file is compiled WITHOUT -amdgpu-mfma-vgpr-form (build.py), unlike the other training kernels.
+#include "nerf_internal.h"
+
+namespace nerf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same product without LDS: both operands of v_mfma_f32_32x32x2_f32 want, per lane, ONE value of a row of the
+// [point][feature] arrays - lane (i, k) takes feature i of point k - so a wave reads its fragments straight from
+// global memory, 16 bytes per lane: the four features 4i..4i+3 of a point are the fragments of FOUR interleaved
+// 32-row tiles (tile t = features 4i + t), and a half-wave reads 512 contiguous bytes. No staging, no transposition,
+// no barrier, no loader waves: a workgroup is 2 x 2 waves of 128 rows x 32 NT columns each (16 NT accumulator
+// registers per lane... 256 at NT = 4, one wave per SIMD), a k-step is two points = 4 NT MFMAs per wave fed by two loads,
+// and the loads run kTnDepth k-steps ahead of their use in kTnDepth explicit register sets (the loop is unrolled by that
+// many, so no set is carried through a copy at the back edge: see gemm_tn_kernel). Every operand byte is read from HBM
+// once per workgroup row block (the staged kernel read dY once per 128 columns).
+//   NT = 4: a job is exactly 256 columns                                     (hidden-width inputs)
+//   NT = 1: a job is at most 64 columns, lanes beyond n_end re-read the last (gamma(x) / gamma(d) columns)
+// blockIdx.y picks the job (GradBatch): the weight gradients of a whole network share a launch, see nerf_internal.h.
+// Rows: Mo must be a multiple of 128 (128 or 256); the wave row of an absent upper half exits at once.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTnDepth = 8;
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes at dword alignment (row strides 63, 283, 319)
+
+template <int NT>
+struct TnCols {
+    float v[NT];
+};
+template <int NT>
+__device__ __forceinline__ TnCols<NT> tn_load_cols(const float* p) {
+    TnCols<NT> r;
+    if constexpr (NT == 4) {
+        const f32x4u q = *(const f32x4u*)p;
+        r.v[0] = q[0]; r.v[1] = q[1]; r.v[2] = q[2]; r.v[3] = q[3];
+    } else {
+        r.v[0] = *p;
+    }
+    return r;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void grad_batch_kernel(const GradBatch b) {
+    const GradJob& g = b.job[blockIdx.y];
+    const int n_begin = g.n_begin, n_end = g.n_end, width = n_end - n_begin;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane >> 5, i = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m_base = 128 * wm;
+    if (m_base >= g.Mo) return;                 // (no barrier anywhere below)
+    const int slice = blockIdx.x;
+    const int c_base = n_begin + 32 * NT * wn;   // this wave's first column
+    if (c_base >= n_end) return;
+    int col = c_base + NT * i;
+    if (col > n_end - NT) col = n_end - NT;     // NT = 1 only: keeps the load inside the row; those outputs are not stored
+    const int64_t p_begin = (int64_t)slice * b.pts_per_slice;
+    int64_t p_end = p_begin + b.pts_per_slice;
+    if (p_end > b.P) p_end = b.P;
+    const int64_t n_pts = p_end > p_begin ? p_end - p_begin : 0;
+    const int n_steps = (int)(n_pts / 2);       // whole k-steps (two points); an odd last point goes through the tail
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
+    float asum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    const float* pa = g.A + (p_begin + k) * g.lda + m_base + 4 * i;
+    const float* pb = g.B + (p_begin + k) * g.ldb + col;
+    const int64_t sa = 2 * (int64_t)g.lda, sb = 2 * (int64_t)g.ldb;
+
+    auto step = [&](const f32x4u& a, const TnCols<NT>& b) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            asum[tm] += a[tm];
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = mfma32(a[tm], b.v[tn], acc[tm][tn]);
+        }
+    };
+
+    f32x4u ra[kTnDepth];
+    TnCols<NT> rb[kTnDepth];
+    int s = 0;
+    if (n_steps >= kTnDepth) {
+#pragma unroll
+        for (int j = 0; j < kTnDepth; ++j) {
+            ra[j] = *(const f32x4u*)pa;
+            rb[j] = tn_load_cols<NT>(pb);
+            pa += sa;
+            pb += sb;
+        }
+        for (; s + 2 * kTnDepth <= n_steps; s += kTnDepth) {
+#pragma unroll
+            for (int j = 0; j < kTnDepth; ++j) {
+                step(ra[j], rb[j]);
+                ra[j] = *(const f32x4u*)pa;      // k-step s + kTnDepth + j, into the registers just consumed
+                rb[j] = tn_load_cols<NT>(pb);
+                pa += sa;
+                pb += sb;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kTnDepth; ++j) step(ra[j], rb[j]);
+        s += kTnDepth;
+    }
+    // the tail: fewer than kTnDepth whole k-steps and possibly a single last point, loads predicated per lane
+    for (int64_t p = p_begin + 2 * (int64_t)s; p < p_end; p += 2) {
+        f32x4u a = {0.0f, 0.0f, 0.0f, 0.0f};
+        TnCols<NT> b;
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) b.v[tn] = 0.0f;
+        if (p + k < p_end) {
+            a = *(const f32x4u*)(g.A + (p + k) * g.lda + m_base + 4 * i);
+            b = tn_load_cols<NT>(g.B + (p + k) * g.ldb + col);
+        }
+        step(a, b);
+    }
+
+    // acc[tm][tn][r] at lane (j = i, h = k): row m_base + 4 (r&3 + 8 (r>>2) + 4 h) + tm, column c_base + NT j + tn
+    float* part = g.part + (int64_t)slice * g.Mo * width - n_begin;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m_base + 4 * ((r & 3) + 8 * (r >> 2) + 4 * k) + tm;
+            float* dst = part + (int64_t)m * width + c_base + NT * i;
+            if constexpr (NT == 4) {
+                const f32x4u v = {acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
+                *(f32x4u*)dst = v;              // NT = 4 blocks lie wholly inside [n_begin, n_end)
+            } else {
+                if (c_base + i < n_end) *dst = acc[tm][0][r];
+            }
+        }
+    if (g.db && wn == 0) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            const float t = asum[tm] + __shfl_xor(asum[tm], 32);
+            if (k == 0) g.dbp[(int64_t)slice * g.Mo + m_base + 4 * i + tm] = t;
+        }
+    }
+}
+
+// part[s][m][c] summed over the slices in order (deterministic) into dW[m][n_begin + c]; thread = four consecutive elements
+// of one job (eight 16-byte loads in flight), the bias gradients behind them
+__global__ __launch_bounds__(256) void grad_batch_reduce_kernel(const GradBatch b) {
+    const GradJob& g = b.job[blockIdx.y];
+    const int width = g.n_end - g.n_begin;
+    const int64_t n_w = (int64_t)g.Mo * width;
+    const int64_t quads = (n_w + 3) / 4;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < quads) {
+        const int64_t e0 = 4 * t;
+        const bool whole = e0 + 4 <= n_w && (n_w & 3) == 0;
+        float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        int k = 0;
+        if (whole) {
+            for (; k + 8 <= b.n_slices; k += 8) {
+                f32x4u v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *(const f32x4u*)(g.part + (int64_t)(k + u) * n_w + e0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) sum[c] += v[u][c];
+            }
+        }
+        for (; k < b.n_slices; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (e0 + c < n_w) sum[c] += g.part[(int64_t)k * n_w + e0 + c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t idx = e0 + c;
+            if (idx < n_w) {
+                float* w = g.dW + (idx / width) * g.ldw + g.n_begin + (idx % width);
+                *w = b.accumulate ? *w + sum[c] : sum[c];   // second pass through a shared network: .grad accumulates (nerf.ipynb:1270)
+            }
+        }
+    } else if (g.db && t - quads < g.Mo) {
+        const int m = (int)(t - quads);
+        float sacc = 0.0f;
+        for (int k = 0; k < b.n_slices; ++k) sacc += g.dbp[(int64_t)k * g.Mo + m];
+        g.db[m] = b.accumulate ? g.db[m] + sacc : sacc;
+    }
+}
+
+hipError_t launch_grad_batch(GradBatch& b, bool wide, float* part, size_t part_floats, float* dbp, size_t dbp_floats,
+                             hipStream_t s) {
+    if (b.n <= 0) return hipSuccess;
+    if (b.n > kMaxGradJobs || b.n_slices <= 0) return hipErrorInvalidValue;
+    size_t used = 0, used_db = 0;
+    int64_t max_threads = 0;
+    for (int j = 0; j < b.n; ++j) {
+        GradJob& g = b.job[j];
+        const int width = g.n_end - g.n_begin;
+        if (g.Mo % 128 != 0 || g.Mo > 256 || width <= 0 || (wide ? width != 256 : width > 64)) return hipErrorInvalidValue;
+        g.part = part + used;
+        g.dbp = dbp + used_db;
+        used += (size_t)b.n_slices * g.Mo * width;
+        used_db += (size_t)b.n_slices * g.Mo;
+        const int64_t th = ((int64_t)g.Mo * width + 3) / 4 + g.Mo;
+        max_threads = th > max_threads ? th : max_threads;
+    }
+    if (used > part_floats || used_db > dbp_floats) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)b.n_slices, (unsigned)b.n);
+    if (wide) hipLaunchKernelGGL(grad_batch_kernel<4>, grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL(grad_batch_kernel<1>, grid, dim3(256), 0, s, b);
+    hipLaunchKernelGGL(grad_batch_reduce_kernel, dim3((unsigned)((max_threads + 255) / 256), (unsigned)b.n), dim3(256), 0, s, b);
+    return hipGetLastError();
+}
+
+}  // namespace nerf

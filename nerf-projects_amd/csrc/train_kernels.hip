@@ -371,8 +371,8 @@ __global__ void reduce_slices_kernel(const float* __restrict__ part, const float
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n_w = (int64_t)Mo * No;
     if (idx < n_w) {
-        // the slices are added in order (deterministic); eight loads are in flight at a time - with one dependent load per
-        // iteration the 33 MB of a layer's partials streamed at a quarter of what the memory system gives
+        // eight loads are in flight at a time - with one dependent load per iteration the partials streamed at a quarter of
+        // what the memory system gives
         float s = 0.0f;
         int k = 0;
         for (; k + 8 <= n_slices; k += 8) {
@@ -393,15 +393,158 @@ __global__ void reduce_slices_kernel(const float* __restrict__ part, const float
     }
 }
 
+// the same sum over MANY slices of a small matrix (gemm_tn_small_kernel: up to 2048 slices of <= 4 x 320): a workgroup owns 16
+// consecutive elements and splits the slices 16 ways (eight loads in flight per thread); the 16 group sums are added in
+// group order through LDS. With one thread per element walking all 2048 slices the pass took 121 us.
+__global__ __launch_bounds__(256) void reduce_many_slices_kernel(const float* __restrict__ part, const float* __restrict__ dbp,
+                                                                 int n_slices, int Mo, int No, float* __restrict__ dW, int ldw,
+                                                                 float* __restrict__ db, int accumulate) {
+    __shared__ float red[16][16];
+    const int64_t n_w = (int64_t)Mo * No, n_all = n_w + Mo;       // weights, then the bias entries (from dbp)
+    const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int64_t idx = (int64_t)blockIdx.x * 16 + e;
+    float sum = 0.0f;
+    if (idx < n_all && (idx < n_w || (db && dbp))) {
+        const float* src = idx < n_w ? part + idx : dbp + (idx - n_w);
+        const int64_t stride = idx < n_w ? n_w : Mo;
+        int k = grp;
+        for (; k + 7 * 16 < n_slices; k += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(k + 16 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
+        }
+        for (; k < n_slices; k += 16) sum += src[(int64_t)k * stride];
+    }
+    red[grp][e] = sum;
+    __syncthreads();
+    if (grp == 0 && idx < n_all) {
+        float t = red[0][e];
+#pragma unroll
+        for (int g2 = 1; g2 < 16; ++g2) t += red[g2][e];
+        if (idx < n_w) {
+            float* w = dW + (idx / No) * ldw + (idx % No);
+            *w = accumulate ? *w + t : t;
+        } else if (db && dbp) {
+            const int m = (int)(idx - n_w);
+            db[m] = accumulate ? db[m] + t : t;
+        }
+    }
+}
+
+// dW of a Linear with at most four output rows (rgb_linear, alpha_linear, a 4- or 5-channel output_linear goes to the
+// staged kernel): a weighted column sum of X, bound by reading X once. Thread = column; the row's dY values are
+// wave-uniform (scalar loads). 145 us per launch on the 256-row MFMA kernel, which computed 252 rows of zeros.
+__global__ __launch_bounds__(256) void gemm_tn_small_kernel(GemmTN g) {
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    const int slice = blockIdx.x;
+    const int64_t p_begin = (int64_t)slice * g.pts_per_slice;
+    int64_t p_end = p_begin + g.pts_per_slice;
+    if (p_end > g.P) p_end = g.P;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, bsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool live = n < g.No;
+    int64_t p = p_begin;
+    for (; p + 8 <= p_end; p += 8) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = live ? g.B[(p + u) * g.ldb + n] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                if (m < g.Mo) {
+                    const float a = g.A[(p + u) * g.lda + m];
+                    acc[m] = fmaf(a, x[u], acc[m]);
+                    bsum[m] += a;
+                }
+    }
+    for (; p < p_end; ++p) {
+        const float x = live ? g.B[p * g.ldb + n] : 0.0f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m < g.Mo) {
+                const float a = g.A[p * g.lda + m];
+                acc[m] = fmaf(a, x, acc[m]);
+                bsum[m] += a;
+            }
+    }
+    if (live)
+        for (int m = 0; m < g.Mo; ++m) g.part[((int64_t)slice * g.Mo + m) * g.No + n] = acc[m];
+    if (g.dbp && blockIdx.y == 0 && threadIdx.x == 0)
+        for (int m = 0; m < g.Mo; ++m) g.dbp[(int64_t)slice * g.Mo + m] = bsum[m];
+}
+
+// NERF_TRAIN_STAGED_DW=1 keeps the LDS-staged kernel for every layer (A/B and fallback)
+static bool staged_dw_requested() {
+    static const bool on = [] {
+        const char* e = getenv("NERF_TRAIN_STAGED_DW");
+        return e && *e && *e != '0';
+    }();
+    return on;
+}
+
+// workgroups per slice of the launch that does the bulk of a layer's dW (the caller sizes the number of slices with it)
+// the weighted-column-sum kernel wants many short slices (its only parallelism besides the columns)
+bool gemm_tn_is_small(int Mo) { return Mo <= 4 && !staged_dw_requested(); }
+
+int gemm_tn_col_blocks(int Mo, int No) {
+    if (gemm_tn_is_small(Mo)) return (No + 255) / 256;
+    if (Mo % 128 == 0 && Mo <= 256 && !staged_dw_requested()) return 1;
+    return (No + 127) / 128;
+}
+
+bool gemm_tn_is_direct(int Mo) { return Mo % 128 == 0 && Mo <= 256 && !staged_dw_requested(); }
+
+// One Linear at a time (the layer-by-layer backward pass, the small layers, the staged fallback); the fused backward pass
+// batches its direct-eligible layers itself (train_api.cpp).
 hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, float* db, int accumulate, hipStream_t s) {
     if (g.Mo <= 0 || g.No <= 0) return hipSuccess;
     if (g.Mo > 256) return hipErrorInvalidValue;
-    static bool raised[64] = {};
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 64 && (e = raise_lds((const void*)gemm_tn_kernel, kTnLds, &raised[dev])) != hipSuccess) return e;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)n_slices, (unsigned)((g.No + 127) / 128)), dim3(512), kTnLds, s, g);
+    if (gemm_tn_is_direct(g.Mo)) {
+        // the hidden-width columns as one job of 256 (for the skip layer they are NOT the first ones: that concatenation puts
+        // gamma(x) in front; the view layer's puts gamma(d) behind), what is left as jobs of up to 64
+        const int wide = g.No >= 256 ? 256 : 0;
+        const int rest = g.No - wide;
+        const int wide_begin = g.narrow_first ? rest : 0;
+        const size_t part_floats = (size_t)n_slices * g.Mo * g.No, dbp_floats = (size_t)n_slices * g.Mo;
+        GradBatch b{};
+        b.n_slices = n_slices;
+        b.accumulate = accumulate;
+        b.P = g.P;
+        b.pts_per_slice = g.pts_per_slice;
+        if (wide) {
+            b.n = 1;
+            b.job[0] = GradJob{g.A, g.lda, g.B, g.ldb, g.Mo, wide_begin, wide_begin + wide, dW, ldw, db, nullptr, nullptr};
+            hipError_t e = launch_grad_batch(b, true, g.part, part_floats, g.dbp, dbp_floats, s);
+            if (e != hipSuccess) return e;
+        }
+        if (rest > 0) {
+            const int nb = g.narrow_first ? 0 : wide;
+            b.n = 0;
+            for (int c = 0; c < rest && b.n < kMaxGradJobs; c += 64, ++b.n)
+                b.job[b.n] = GradJob{g.A, g.lda, g.B, g.ldb, g.Mo, nb + c, nb + (c + 64 < rest ? c + 64 : rest), dW, ldw,
+                                     (!wide && c == 0) ? db : nullptr, nullptr, nullptr};
+            if ((rest + 63) / 64 > kMaxGradJobs) return hipErrorInvalidValue;
+            // (the wide job's partials have been reduced by now: stream order)
+            return launch_grad_batch(b, false, g.part, part_floats, g.dbp, dbp_floats, s);
+        }
+        return hipSuccess;
+    }
+    if (gemm_tn_is_small(g.Mo)) {
+        hipLaunchKernelGGL(gemm_tn_small_kernel, dim3((unsigned)n_slices, (unsigned)((g.No + 255) / 256)), dim3(256), 0, s, g);
+        const int64_t n_all = (int64_t)g.Mo * g.No + g.Mo;
+        hipLaunchKernelGGL(reduce_many_slices_kernel, dim3((unsigned)((n_all + 15) / 16)), dim3(256), 0, s, g.part, g.dbp,
+                           n_slices, g.Mo, g.No, dW, ldw, db, accumulate);
+        return hipGetLastError();
+    } else {
+        static bool raised[64] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64 && (e = raise_lds((const void*)gemm_tn_kernel, kTnLds, &raised[dev])) != hipSuccess) return e;
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)n_slices, (unsigned)((g.No + 127) / 128)), dim3(512), kTnLds, s, g);
+    }
     const int64_t total = (int64_t)g.Mo * g.No + g.Mo;
     hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g.part, g.dbp, n_slices,
                        g.Mo, g.No, dW, ldw, db, accumulate);
