@@ -871,6 +871,34 @@ def test_train_gradients_match_autograd(N, weights_pair):
     assert np.array_equal(net_c.state_dict()["pts_linears.0.weight"].numpy(), weights_pair[0]["pts_linears.0.weight"])
 
 
+def test_train_gradients_of_ragged_batches_add_up(N, weights_pair):
+    """The weight-gradient kernels cut the points of a pass into slices of two-point steps (csrc/train_dw_kernel.hip): odd
+    point counts, slices that end mid-step and passes shorter than the prefetch depth take their tail paths, which the
+    32-ray fixtures (2 048 / 6 144 points) never reach. img2mse is a mean over rays (nerf_helpers.py:12), so without
+    noise the gradient of a batch is the ray-weighted mean of the gradients of its parts: 37 rays x 63 (+128) samples
+    = 2 331 / 7 067 points against its parts of 32 and 5 rays (315 / 955 points)."""
+    g, _, _, kw, _, _ = _train_setup(N, weights_pair)
+    kw.update(N_samples=63, perturb=0.0, raw_noise_std=0.0)
+    rng = np.random.default_rng(5)
+    rays = np.concatenate([g["rays"], g["rays"][:5] + np.float32(0.01)]).astype(np.float32)
+    rays[:, 8:11] = rays[:, 3:6] / np.linalg.norm(rays[:, 3:6], axis=1, keepdims=True)
+    target = rng.random((37, 3), dtype=np.float32)
+
+    def grads(lo, hi):
+        nc, nf = make_net(N, weights_pair[0]), make_net(N, weights_pair[1])
+        k2 = dict(kw, network_fn=nc, network_fine=nf)
+        opt = N.Adam([nc, nf], lr=5e-4)
+        N.train_on_batch(800, 800, None, (gpu(rays[lo:hi, 0:3]), gpu(rays[lo:hi, 3:6])), gpu(target[lo:hi]), opt,
+                         apply_update=False, **k2)
+        return {f"{t}.{k}": v.numpy().astype(np.float64) for t, n in (("c", nc), ("f", nf)) for k, v in n.grad_dict().items()}
+
+    whole, a, b = grads(0, 37), grads(0, 32), grads(32, 37)
+    for k in whole:
+        want = (32.0 * a[k] + 5.0 * b[k]) / 37.0
+        scale = np.abs(want).max() + 1e-12
+        assert np.abs(whole[k] - want).max() <= 2e-5 * scale, (k, np.abs(whole[k] - want).max() / scale)
+
+
 @pytest.mark.parametrize("tag,n_imp", [("shared", 128), ("coarse", 0)])
 def test_train_gradients_shared_and_single_network(N, weights_pair, tag, n_imp):
     """The other two configurations create_nerf can hand to the loop (nerf.ipynb:887-896, :471): network_fine=None with
