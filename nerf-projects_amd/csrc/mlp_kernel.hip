@@ -469,6 +469,32 @@ __device__ __forceinline__ void mask_tiles(f32x16 (&dst)[8], const f32x16 (&g)[8
             for (int e = 0; e < 4; ++e) dst[i][4 * q + e] = v[e] > 0.0f ? g[i][4 * q + e] : 0.0f;
         }
 }
+// one tile of the kept activation (feature columns 32 i .. 32 i + 31), requested early: see the backward kernel
+__device__ __forceinline__ void load_tile(const float* base, int ld, f32x16& t, int i, int64_t pt, int h) {
+    const float* row = base + (uint32_t)((uint32_t)pt * (uint32_t)ld + 4u * (uint32_t)h) + 32 * i;
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);   // wave-uniform
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float* p = row + 8 * q;
+        if (vec) {
+            const f32x4 v = *(const f32x4*)p;
+            t[4 * q] = v[0];
+            t[4 * q + 1] = v[1];
+            t[4 * q + 2] = v[2];
+            t[4 * q + 3] = v[3];
+        } else {
+            t[4 * q] = p[0];
+            t[4 * q + 1] = p[1];
+            t[4 * q + 2] = p[2];
+            t[4 * q + 3] = p[3];
+        }
+    }
+}
+// dst = g * [kept > 0], in the registers the activation was loaded into
+__device__ __forceinline__ void mask_tile(f32x16& kept_then_dst, const f32x16& g) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) kept_then_dst[r] = kept_then_dst[r] > 0.0f ? g[r] : 0.0f;
+}
 template <int N>
 __device__ __forceinline__ void zero_tiles(f32x16 (&t)[8]) {
 #pragma unroll
@@ -522,25 +548,38 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
         activate<8, false>(hid, acc);
 
         // d h_{D-1} = W_feature^T d feature + d sigma * w_alpha (alpha row: bias-block tiles 8D+14+t), then its mask
+        // The ReLU mask of the layer below is the activation the forward pass kept: 1 KB per point, 128 KB per workgroup
+        // and layer. Read at the layer boundary it stalls the matrix pipe for as long as HBM takes to deliver it (a fifth
+        // of a layer's time, measured); instead tile kt of it is requested behind the barrier of chunk kt + 1, into the
+        // registers of the gradient tile that chunk kt has just finished with, and only tile 7 is waited for in the open.
         zero_tiles<8>(acc);
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt)
-            chunk_ktile8(pipe, cur, acc, hid[kt], [&]() { store_tile(b.out.feat, b.out.feat_ld, hid[kt], kt, pt, h, live); });
+            chunk_ktile8(pipe, cur, acc, hid[kt], [&]() {
+                store_tile(b.out.feat, b.out.feat_ld, hid[kt], kt, pt, h, live);
+                if (kt >= 1) load_tile(b.fwd.h[b.D - 1], b.fwd.h_ld[b.D - 1], hid[kt - 1], kt - 1, pt, h);
+            });
+        load_tile(b.fwd.h[b.D - 1], b.fwd.h_ld[b.D - 1], hid[7], 7, pt, h);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const f32x16 wa = *(const f32x16*)(bias_lds + ((8 * b.D + 14 + t) * 2 + h) * 16);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(dsig, wa[r], acc[t][r]);
+            mask_tile(hid[t], acc[t]);
         }
-        mask_tiles<8>(hid, acc, b.fwd.h[b.D - 1], b.fwd.h_ld[b.D - 1], pt, h);
 
         // trunk: d h_{i-1} = W_i[:, hidden]^T d z_i, masked by layer i-1's ReLU
         for (int i = b.D - 1; i >= 1; --i) {
             zero_tiles<8>(acc);
 #pragma unroll
             for (int kt = 0; kt < 8; ++kt)
-                chunk_ktile8(pipe, cur, acc, hid[kt], [&]() { store_tile(b.out.h[i], b.out.h_ld[i], hid[kt], kt, pt, h, live); });
-            mask_tiles<8>(hid, acc, b.fwd.h[i - 1], b.fwd.h_ld[i - 1], pt, h);
+                chunk_ktile8(pipe, cur, acc, hid[kt], [&]() {
+                    store_tile(b.out.h[i], b.out.h_ld[i], hid[kt], kt, pt, h, live);
+                    if (kt >= 1) load_tile(b.fwd.h[i - 1], b.fwd.h_ld[i - 1], hid[kt - 1], kt - 1, pt, h);
+                });
+            load_tile(b.fwd.h[i - 1], b.fwd.h_ld[i - 1], hid[7], 7, pt, h);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) mask_tile(hid[t], acc[t]);
         }
         store_tiles<8>(b.out.h[0], b.out.h_ld[0], hid, pt, h, live);     // d z_0: nothing left to ride behind
     }
