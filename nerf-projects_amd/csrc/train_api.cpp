@@ -77,8 +77,8 @@ size_t pass_floats(const PackedNet& net, int64_t P) {
     const nerf_arch& a = net.arch;
     size_t f = (size_t)P * a.input_ch;
     f += (size_t)a.D * ((size_t)P * a.W + 64);      // Pass::dz (fused backward)
-    for (int i = 0; i < a.D; ++i) f += (size_t)P * (a.W + a.input_ch);
-    f += (size_t)P * (a.W + a.input_ch_views) + (size_t)P * (a.W / 2);
+    for (int i = 0; i < a.D; ++i) f += (size_t)P * (a.W + a.input_ch + 3) + 4;
+    f += (size_t)P * (a.W + a.input_ch_views + 3) + (size_t)P * (a.W / 2);
     f += (size_t)P * 8 * 2;                     // raw, d_raw (<= 8 channels budgeted... out_ch <= 32 handled below)
     f += (size_t)P * 2 * (net.out_ch > 8 ? net.out_ch : 0);
     f += (size_t)P * a.W * 2 + (size_t)P * (a.W / 2);
@@ -100,11 +100,15 @@ void carve_pass(Arena& ar, Pass& ps) {
     for (int i = 0; i < a.D; ++i) {
         const bool next_cat = (i + 1 < a.D) && ((net.skip_in_mask >> (i + 1)) & 1);
         if (next_cat) {
-            float* cat = ar.take((size_t)P * (a.W + a.input_ch));   // [gamma(x) | h_i] (nerf.py:79-80)
-            ps.h[i] = cat + a.input_ch;
-            ps.h_ld[i] = a.W + a.input_ch;
-            ps.in[i + 1] = cat;
-            ps.in_ld[i + 1] = a.W + a.input_ch;
+            // [gamma(x) | h_i] (nerf.py:79-80), rows padded IN FRONT so that h_i starts on a 16-byte boundary and the row
+            // stride is a multiple of four floats: the fused kernels then write and read h_i with 16-byte accesses (63
+            // leading columns and a stride of 319 floats meant four dword stores for each of them)
+            const int pad = (4 - a.input_ch % 4) % 4, ld = a.W + a.input_ch + pad;
+            float* cat = ar.take((size_t)P * ld + 4);
+            ps.in[i + 1] = cat + pad;
+            ps.in_ld[i + 1] = ld;
+            ps.h[i] = cat + pad + a.input_ch;
+            ps.h_ld[i] = ld;
         } else {
             ps.h[i] = ar.take((size_t)P * a.W);
             ps.h_ld[i] = a.W;
@@ -115,7 +119,7 @@ void carve_pass(Arena& ar, Pass& ps) {
         }
     }
     if (a.use_viewdirs) {
-        ps.vcat_ld = a.W + a.input_ch_views;
+        ps.vcat_ld = (a.W + a.input_ch_views + 3) / 4 * 4;            // row stride a multiple of four floats, as above
         ps.vcat = ar.take((size_t)P * ps.vcat_ld);                    // [feature | gamma(dir)] (nerf.py:93)
         ps.hv = ar.take((size_t)P * (a.W / 2));
     }
