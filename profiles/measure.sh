@@ -14,4 +14,5 @@ timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1 && echo s ok &&
 timeout -k 10 200 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_l2 -- $B > $O/pmc_l2.log 2>&1 && echo l ok &&
 timeout -k 10 400 python3 $R/profiles/shard_projection.py > $O/shard_projection.log 2>&1 && echo shards ok &&
-timeout -k 10 200 python3 $R/bench_train.py > $O/bench_train.json 2>> $O/bench_n1.err && echo train ok
+timeout -k 10 200 python3 $R/bench_train.py --iters 40 > $O/bench_train.json 2>> $O/bench_n1.err && echo train ok &&
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -- python3 $R/bench_train.py --iters 20 --warmup 3 > $O/train_stats.log 2>&1 && echo train stats ok
