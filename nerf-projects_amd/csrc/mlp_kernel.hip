@@ -288,6 +288,39 @@ __device__ __forceinline__ void store_tile(float* base, int ld, const f32x16& t,
     }
 }
 
+// The hooks that ride inside the chunk loop use these instead: straight-line code. store_tile()'s tests (buffer present?
+// rows 16-byte aligned? lane past the end?) are branches in the middle of the pinned MFMA stream - 490 of them in the
+// training forward kernel, which ran a tile in 306 us against 256 us for the store-free inference kernel while the stores
+// themselves accounted for 1 % (ablation). Here the launcher guarantees present, 16-byte aligned buffers (training_rows_ok)
+// and lanes past the end write what the lane of the last point writes (they recompute that point: same values, same
+// address). base: wave-uniform; off: this lane's element offset of (point, 4 h), 32 bits (the launchers bound n_points).
+struct RowRef {
+    float* base;
+    uint32_t off;
+};
+__device__ __forceinline__ RowRef row_ref(const float* base, int ld, int64_t pt, int h) {
+    return RowRef{const_cast<float*>(base), (uint32_t)pt * (uint32_t)ld + 4u * (uint32_t)h};
+}
+__device__ __forceinline__ void store_tile_at(const RowRef& r, const f32x16& t, int i) {
+    float* p = r.base + r.off + 32 * i;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(f32x4*)(p + 8 * q) = f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+}
+__device__ __forceinline__ void load_tile_at(const RowRef& r, f32x16& t, int i) {
+    const float* p = r.base + r.off + 32 * i;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *(const f32x4*)(p + 8 * q);
+        t[4 * q] = v[0];
+        t[4 * q + 1] = v[1];
+        t[4 * q + 2] = v[2];
+        t[4 * q + 3] = v[3];
+    }
+}
+static bool training_rows_ok(const void* base, int ld) {
+    return base != nullptr && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0;
+}
+
 // ---- the kernel -------------------------------------------------------------------------
 template <int MODE, bool STORE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -340,11 +373,11 @@ void nerf_mlp_kernel(const MlpLaunch a) {
         load_bias<8>(acc, bias_lds, is_feature ? 8 * a.D + 1 : 8 * i, h);
         // (training: tile kt of the previous layer's output - this chunk's B operand - goes to memory behind this chunk's
         // barrier)
+        const RowRef keep = STORE ? row_ref(a.st.h[i - 1], a.st.h_ld[i - 1], pt, h) : RowRef{nullptr, 0u};
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) {
             if constexpr (STORE)
-                chunk_ktile8(pipe, cur, acc, hid[kt],
-                             [&]() { store_tile(a.st.h[i - 1], a.st.h_ld[i - 1], hid[kt], kt, pt, h, live); });
+                chunk_ktile8(pipe, cur, acc, hid[kt], [&]() { store_tile_at(keep, hid[kt], kt); });
             else
                 chunk_ktile8(pipe, cur, acc, hid[kt]);
         }
@@ -374,12 +407,13 @@ void nerf_mlp_kernel(const MlpLaunch a) {
     if (a.use_viewdirs) {
         // views_linears[0] on cat[feature, gamma(dir)] (nerf.py:93-98): 4 output tiles
         load_bias<4>(acc, bias_lds, 8 * a.D + 9, h);
+        const RowRef keep = STORE ? row_ref(a.st.feat, a.st.feat_ld, pt, h) : RowRef{nullptr, 0u};
 #pragma unroll
         for (int kp = 0; kp < 4; ++kp) {
             if constexpr (STORE)
                 chunk_pair4(pipe, cur, acc, hid[2 * kp], hid[2 * kp + 1], [&]() {
-                    store_tile(a.st.feat, a.st.feat_ld, hid[2 * kp], 2 * kp, pt, h, live);
-                    store_tile(a.st.feat, a.st.feat_ld, hid[2 * kp + 1], 2 * kp + 1, pt, h, live);
+                    store_tile_at(keep, hid[2 * kp], 2 * kp);
+                    store_tile_at(keep, hid[2 * kp + 1], 2 * kp + 1);
                 });
             else
                 chunk_pair4(pipe, cur, acc, hid[2 * kp], hid[2 * kp + 1]);
@@ -542,9 +576,12 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
         // every gradient tile goes to memory behind the barrier of the chunk that contracts over it (see run_steps)
         // d feature = W_views[:, :W]^T d(view pre-activation)
         zero_tiles<8>(acc);
+        {
+            const RowRef out = row_ref(b.out.hv, b.out.hv_ld, pt, h);
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-            chunk_ktile8(pipe, cur, acc, hid[kt], [&]() { store_tile(b.out.hv, b.out.hv_ld, hid[kt], kt, pt, h, live); });
+            for (int kt = 0; kt < 4; ++kt)
+                chunk_ktile8(pipe, cur, acc, hid[kt], [&]() { store_tile_at(out, hid[kt], kt); });
+        }
         activate<8, false>(hid, acc);
 
         // d h_{D-1} = W_feature^T d feature + d sigma * w_alpha (alpha row: bias-block tiles 8D+14+t), then its mask
@@ -553,13 +590,17 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
         // of a layer's time, measured); instead tile kt of it is requested behind the barrier of chunk kt + 1, into the
         // registers of the gradient tile that chunk kt has just finished with, and only tile 7 is waited for in the open.
         zero_tiles<8>(acc);
+        {
+            const RowRef out = row_ref(b.out.feat, b.out.feat_ld, pt, h);
+            const RowRef kept = row_ref(b.fwd.h[b.D - 1], b.fwd.h_ld[b.D - 1], pt, h);
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt)
-            chunk_ktile8(pipe, cur, acc, hid[kt], [&]() {
-                store_tile(b.out.feat, b.out.feat_ld, hid[kt], kt, pt, h, live);
-                if (kt >= 1) load_tile(b.fwd.h[b.D - 1], b.fwd.h_ld[b.D - 1], hid[kt - 1], kt - 1, pt, h);
-            });
-        load_tile(b.fwd.h[b.D - 1], b.fwd.h_ld[b.D - 1], hid[7], 7, pt, h);
+            for (int kt = 0; kt < 8; ++kt)
+                chunk_ktile8(pipe, cur, acc, hid[kt], [&]() {
+                    store_tile_at(out, hid[kt], kt);
+                    if (kt >= 1) load_tile_at(kept, hid[kt - 1], kt - 1);
+                });
+            load_tile_at(kept, hid[7], 7);
+        }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const f32x16 wa = *(const f32x16*)(bias_lds + ((8 * b.D + 14 + t) * 2 + h) * 16);
@@ -571,13 +612,15 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
         // trunk: d h_{i-1} = W_i[:, hidden]^T d z_i, masked by layer i-1's ReLU
         for (int i = b.D - 1; i >= 1; --i) {
             zero_tiles<8>(acc);
+            const RowRef out = row_ref(b.out.h[i], b.out.h_ld[i], pt, h);
+            const RowRef kept = row_ref(b.fwd.h[i - 1], b.fwd.h_ld[i - 1], pt, h);
 #pragma unroll
             for (int kt = 0; kt < 8; ++kt)
                 chunk_ktile8(pipe, cur, acc, hid[kt], [&]() {
-                    store_tile(b.out.h[i], b.out.h_ld[i], hid[kt], kt, pt, h, live);
-                    if (kt >= 1) load_tile(b.fwd.h[i - 1], b.fwd.h_ld[i - 1], hid[kt - 1], kt - 1, pt, h);
+                    store_tile_at(out, hid[kt], kt);
+                    if (kt >= 1) load_tile_at(kept, hid[kt - 1], kt - 1);
                 });
-            load_tile(b.fwd.h[i - 1], b.fwd.h_ld[i - 1], hid[7], 7, pt, h);
+            load_tile_at(kept, hid[7], 7);
 #pragma unroll
             for (int t = 0; t < 8; ++t) mask_tile(hid[t], acc[t]);
         }
@@ -590,6 +633,11 @@ hipError_t launch_mlp_bwd(const MlpBwdLaunch& b, hipStream_t s) {
     if (b.n_points <= 0) return hipSuccess;
     if (b.n_chunks != 12 + 8 * (b.D - 1) || b.C < 4) return hipErrorInvalidValue;
     if (b.n_points > (int64_t)1 << 22) return hipErrorInvalidValue;      // 32-bit element offsets in load/store_tiles
+    // the hooks inside the chunk loop are unconditional 16-byte accesses (RowRef)
+    bool rows_ok = training_rows_ok(b.out.hv, b.out.hv_ld) && training_rows_ok(b.out.feat, b.out.feat_ld) &&
+                   training_rows_ok(b.fwd.hv, b.fwd.hv_ld);
+    for (int i = 0; i < b.D; ++i) rows_ok = rows_ok && training_rows_ok(b.out.h[i], b.out.h_ld[i]) && training_rows_ok(b.fwd.h[i], b.fwd.h_ld[i]);
+    if (!rows_ok) return hipErrorInvalidValue;
     const int64_t tiles = (b.n_points + kPointsPerGroup - 1) / kPointsPerGroup;
     static int n_cu[64] = {};
     int dev = 0;
@@ -633,6 +681,11 @@ hipError_t launch_mlp(const MlpLaunch& a, int mode, hipStream_t s) {
     static bool raised[64][4] = {};
     if (mode < 0 || mode > 2) return hipErrorInvalidValue;
     if (a.store && (mode != kInputRays || a.n_points > (int64_t)1 << 22)) return hipErrorInvalidValue;   // training forward: ray records; 32-bit element offsets in store_tiles
+    if (a.store) {   // the hooks inside the chunk loop are unconditional 16-byte stores (RowRef)
+        bool rows_ok = !a.use_viewdirs || (training_rows_ok(a.st.feat, a.st.feat_ld) && training_rows_ok(a.st.hv, a.st.hv_ld));
+        for (int i = 0; i < a.D; ++i) rows_ok = rows_ok && training_rows_ok(a.st.h[i], a.st.h_ld[i]);
+        if (!rows_ok) return hipErrorInvalidValue;
+    }
     typedef void (*kernel_t)(const MlpLaunch);
     static const kernel_t table[4] = {nerf_mlp_kernel<kInputEmbedded>, nerf_mlp_kernel<kInputPoints>,
                                       nerf_mlp_kernel<kInputRays>, nerf_mlp_kernel<kInputRays, true>};
