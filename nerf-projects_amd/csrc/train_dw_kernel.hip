@@ -15,18 +15,18 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // [point][feature] arrays - lane (i, k) takes feature i of point k - so a wave reads its fragments straight from
 // global memory, 16 bytes per lane: the four features 4i..4i+3 of a point are the fragments of FOUR interleaved
 // 32-row tiles (tile t = features 4i + t), and a half-wave reads 512 contiguous bytes. No staging, no transposition,
-// no barrier, no loader waves: a workgroup is 2 x 2 waves of 128 rows x 32 NT columns each (16 NT accumulator
-// registers per lane... 256 at NT = 4, one wave per SIMD), a k-step is two points = 4 NT MFMAs per wave fed by two loads,
-// and the loads run kTnDepth k-steps ahead of their use in kTnDepth explicit register sets (the loop is unrolled by that
-// many, so no set is carried through a copy at the back edge: see gemm_tn_kernel). Every operand byte is read from HBM
-// once per workgroup row block (the staged kernel read dY once per 128 columns).
+// no barrier, no loader waves: a workgroup is 2 x 2 waves of 128 rows x 32 NT columns each (64 NT accumulator
+// registers per lane: 256 at NT = 4, hence one wave per SIMD), a k-step is two points = 4 NT MFMAs per wave fed by two
+// loads, and the loads of kTnDepth k-steps are in flight, in kTnDepth register sets the loop is unrolled over (hipcc
+// issues a group's loads at its head: a whole group of MFMAs, 8 192 matrix-pipe cycles at NT = 4, for them to arrive).
+// Every operand byte is read from HBM once per job (the staged kernel read dY once per 128 columns).
 //   NT = 4: a job is exactly 256 columns                                     (hidden-width inputs)
 //   NT = 1: a job is at most 64 columns, lanes beyond n_end re-read the last (gamma(x) / gamma(d) columns)
 // blockIdx.y picks the job (GradBatch): the weight gradients of a whole network share a launch, see nerf_internal.h.
 // Rows: Mo must be a multiple of 128 (128 or 256); the wave row of an absent upper half exits at once.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTnDepth = 8;
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes at dword alignment (row strides 63, 283, 319)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes at dword alignment (columns 63.. of a concat row)
 
 template <int NT>
 struct TnCols {
