@@ -464,6 +464,11 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
                 split_tile(xd, dd, pd.sc);
             }
             chunk_ktile4(pipe, cur, accB, xd);
+            unsigned bad;     // raw inputs re-read (a value kept across the view layer costs the step a register): requested
+            {                 // here, behind the last MFMA chunk, so that the round trip runs under the colour head's arithmetic
+                f32x16 x0, x1, dd;
+                load_inputs<MODE, false, false>(a, pt, h, x0, x1, dd, nullptr, &bad);
+            }
             f32x16 y[4];
             finish_views(y, accB, bias0 + 128 * (8 * a.D + 9), lds_scalar(layer_tab + 4 * (a.D + 1)) * pow2f(-pd.t_out));
             // rgb_linear (nerf.py:101): three rows over the 128-wide view layer
@@ -471,11 +476,6 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             const float r0 = row_dot4(y, bias0 + 128 * (8 * a.D + 22)) + lds_scalar(rb);
             const float r1 = row_dot4(y, bias0 + 128 * (8 * a.D + 26)) + lds_scalar(rb + 1);
             const float r2 = row_dot4(y, bias0 + 128 * (8 * a.D + 30)) + lds_scalar(rb + 2);
-            unsigned bad;     // raw inputs re-read here: a value kept across the view layer costs the step a register
-            {
-                f32x16 x0, x1, dd;
-                load_inputs<MODE, false, false>(a, pt, h, x0, x1, dd, nullptr, &bad);
-            }
             if (live && h == 0) {
                 f32x4 o = {r0, r1, r2, sigma};   // outputs = cat[rgb, alpha] (nerf.py:106)
                 if (bad) {                       // NaN / Inf inputs propagate as through F.relu (see kBadXyz)

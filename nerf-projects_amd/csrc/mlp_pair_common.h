@@ -103,7 +103,13 @@ struct Frag4 {
 // chunks waits for lgkmcnt(0).
 template <int OFF>
 __device__ __forceinline__ void frag_issue(f32x4& q, unsigned addr) {
+#ifdef NERF_FRAG_VGPR
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(q) : "v"(addr), "n"(OFF) : "memory");
+#else
+    // into the accumulator half of the register file: an MFMA takes its A operand from there as well, and the 32
+    // registers of the double-buffered fragments are 32 vector registers the conversion does not have to fight for
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&a"(q) : "v"(addr), "n"(OFF) : "memory");
+#endif
 }
 template <int N>
 __device__ __forceinline__ void lgkm_wait() {
