@@ -14,16 +14,20 @@ queue is kept (a back edge re-enters with the same pattern).
 import re
 import sys
 
-REG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
+NUM = r"(0x[0-9a-fA-F]+|\d+)"
+REG = re.compile(r"\b([va])\[" + NUM + ":" + NUM + r"\]|\b([va])\[" + NUM + r"\]|\b([va])(\d+)\b")
 
 
 def regs(text):
+    """Registers named in an operand list: v12, a[4:7], and the forms hand-allocated code is printed in (v[0xb0:0xb3], a[0x83])."""
     out = set()
     for m in REG.finditer(text):
         if m.group(1):
-            out.update((m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1))
+            out.update((m.group(1), i) for i in range(int(m.group(2), 0), int(m.group(3), 0) + 1))
+        elif m.group(4):
+            out.add((m.group(4), int(m.group(5), 0)))
         else:
-            out.add((m.group(4), int(m.group(5))))
+            out.add((m.group(6), int(m.group(7))))
     return out
 
 
