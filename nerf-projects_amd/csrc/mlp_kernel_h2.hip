@@ -296,7 +296,8 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
 
-    PipeH pipe{(const char*)a.stream_h2, ring_lds, 0, 0, a.n_chunks, wave, lane, nullptr, nullptr, nullptr, nullptr};
+    PipeH pipe{(const char*)a.stream_h2, ring_lds, 0, 0, a.n_chunks, wave, lane, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0};
+    pipe_start(pipe);
 #ifdef NERF_STAMPS
     pipe.st = Stamper{a.stamps, 0, -1, 0, blockIdx.x == 0 && wave == 0 && a.stamps != nullptr};
 #endif
@@ -328,7 +329,9 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
     const int n_layers = a.use_viewdirs ? a.D + 1 : a.D;
     const int64_t n_tiles = (a.n_points + kPointsPerGroup - 1) / kPointsPerGroup;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#ifdef NERF_STAMPS
         pipe.c = 0;
+#endif
         const int64_t tile0 = tile * kPointsPerGroup + wave * kPointsPerWave;
         const int64_t pt_raw = tile0 + (lane & 31);
         const int64_t pt = pt_raw < a.n_points ? pt_raw : a.n_points - 1;

@@ -58,6 +58,13 @@ struct PipeH {
     const char* g_second;
     char* l_first;
     char* l_second;
+    // carried from chunk to chunk (consume_chunk): what a chunk needs beyond its predecessor's values is one ring slot and
+    // one stream position - recomputing every address from (c, b) was 27 instructions between the last MFMA of a chunk and
+    // the first of the next, with a single MFMA left in the matrix pipe to cover them
+    unsigned fr;            // LDS address of this lane's fragments in the current chunk's slot
+    const char* g2;         // this lane's source of chunk c + 2 and of chunk c + 3 (middle of the wave's share)
+    const char* g3;
+    int c3;                 // (c + 3) mod n: the stream wraps into the next tile's
 #ifdef NERF_STAMPS
     Stamper st;
 #endif
@@ -146,7 +153,7 @@ __device__ __forceinline__ void run_steps(PipeH& p, Frag4& cur, unsigned fr, uns
         {
             constexpr int per = 8 / NSTEP;
             if constexpr (S < NSTEP / 2) prefetch_pieces<S * per, (S + 1) * per>(p.g_first, p.l_first);
-            else prefetch_pieces<(S - NSTEP / 2) * per, (S - NSTEP / 2 + 1) * per>(p.g_second, p.l_second);
+            else prefetch_pieces<(S - NSTEP / 2) * per - 4, (S - NSTEP / 2 + 1) * per - 4>(p.g_second, p.l_second);
         }
 #endif
         NERF_FENCE();
@@ -198,19 +205,35 @@ __device__ __forceinline__ unsigned lds_byte_addr(const void* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
 
+__device__ __forceinline__ void pipe_start(PipeH& p) {
+    static_assert(kRingH == 4, "ring slots are advanced with & 3");
+    p.b = 0;
+    p.fr = lds_byte_addr(p.lds) + p.lane * 16;
+    p.g2 = piece_src(p, 2 < p.n ? 2 : 2 % p.n) + 4096;      // (biased by half a wave's share: see consume_chunk)
+    p.c3 = 3 < p.n ? 3 : 3 % p.n;
+    p.g3 = piece_src(p, p.c3) + 4096;
+}
 template <int NSTEP, int NB, class Body>
 __device__ __forceinline__ void consume_chunk(PipeH& p, Frag4& cur, Body body) {
-    const unsigned fr = lds_byte_addr(p.lds + p.b * kChunkBytes) + p.lane * 16;
-    const unsigned fr_next = lds_byte_addr(p.lds + ringh_next(p.b, 1) * kChunkBytes) + p.lane * 16;
-    const int c2 = p.c + 2 < p.n ? p.c + 2 : p.c + 2 - p.n;   // wraps into the next tile's stream
-    const int c3 = p.c + 3 < p.n ? p.c + 3 : p.c + 3 - p.n;
-    p.g_first = piece_src(p, c2) + 4096;
-    p.l_first = piece_dst(p, ringh_next(p.b, 2)) + 4096;
-    p.g_second = piece_src(p, c3);
-    p.l_second = piece_dst(p, ringh_next(p.b, 3));
+    const int b1 = (p.b + 1) & 3, b2 = (p.b + 2) & 3, b3 = (p.b + 3) & 3;
+    const unsigned fr = p.fr;
+    const unsigned fr_next = lds_byte_addr(p.lds) + p.lane * 16 + b1 * kChunkBytes;
+    // both halves of a wave's share are addressed from its MIDDLE: pieces 4..7 at immediate offsets 0..3 KiB, pieces 0..3 at
+    // -4..-1 KiB (the offset field is signed, 13 bits, and moves the LDS address along) - no pointer arithmetic per chunk
+    p.g_first = p.g2;
+    p.l_first = piece_dst(p, b2) + 4096;
+    p.g_second = p.g3;
+    p.l_second = piece_dst(p, b3) + 4096;
     run_steps<0, NSTEP, NB>(p, cur, fr, fr_next, body);
+#ifdef NERF_STAMPS
     ++p.c;
-    p.b = ringh_next(p.b, 1);
+#endif
+    p.b = b1;
+    p.fr = fr_next;
+    p.g2 = p.g3;
+    p.c3 = p.c3 + 1 == p.n ? 0 : p.c3 + 1;
+    // (one 64-bit add fewer with a carried per-lane base pointer measured 1 % SLOWER: code placement, guide rule 27)
+    p.g3 = p.stream + (size_t)(unsigned)p.c3 * kChunkBytes + (p.wave * 8192 + p.lane * 16 + 4096);
 }
 
 // ---- per-point scaling and the fp16 split --------------------------------------------------
