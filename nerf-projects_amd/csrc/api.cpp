@@ -332,7 +332,7 @@ int nerf_load_weights(nerf_ctx* c, int slot, const nerf_arch* arch, const float*
         set_error("internal: %zu chunk scale groups for %d chunks", layer_of.size(), nc);
         return NERF_E_INVALID;
     }
-    if (e == hipSuccess) e = hipMalloc((void**)&net.d_stream_h2, (size_t)nc * kChunkBytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&net.d_stream_h2, (size_t)(nc + kStreamTailChunks) * kChunkBytes);
     if (e == hipSuccess) e = hipMalloc((void**)&net.d_descale, (kMaxDepth + 3) * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&net.d_chunk_layer, (size_t)nc * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&net.d_chunk_max, (size_t)nc * sizeof(float));

@@ -332,6 +332,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
 #ifdef NERF_STAMPS
         pipe.c = 0;
 #endif
+        pipe_tile_start(pipe);
         const int64_t tile0 = tile * kPointsPerGroup + wave * kPointsPerWave;
         const int64_t pt_raw = tile0 + (lane & 31);
         const int64_t pt = pt_raw < a.n_points ? pt_raw : a.n_points - 1;
@@ -668,7 +669,11 @@ hipError_t launch_convert_stream_h2(const float* stream, const int* chunk_layer,
     hipLaunchKernelGGL(chunk_absmax_kernel, dim3(n_chunks), dim3(256), 0, s, stream, chunk_max);
     hipLaunchKernelGGL(convert_stream_h2_kernel, dim3(n_chunks), dim3(256), 0, s, stream, chunk_layer, chunk_max,
                        n_chunks, out, descale);
-    return hipGetLastError();
+    // the kernel's weight ring runs three chunks ahead, across tile boundaries: the stream is followed by a copy of its
+    // head, so that a position only ever advances within a tile (kStreamTailChunks, PipeH)
+    if (n_chunks < kStreamTailChunks) return hipErrorInvalidValue;
+    return hipMemcpyAsync(out + (size_t)n_chunks * kChunkFloats, out, (size_t)kStreamTailChunks * kChunkBytes,
+                          hipMemcpyDeviceToDevice, s);
 }
 
 }  // namespace nerf

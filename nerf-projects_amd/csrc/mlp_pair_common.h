@@ -63,8 +63,9 @@ struct PipeH {
     // the first of the next, with a single MFMA left in the matrix pipe to cover them
     unsigned fr;            // LDS address of this lane's fragments in the current chunk's slot
     const char* g2;         // this lane's source of chunk c + 2 and of chunk c + 3 (middle of the wave's share)
-    const char* g3;
-    int c3;                 // (c + 3) mod n: the stream wraps into the next tile's
+    const char* g3;         // the stream is followed by a copy of its first three chunks (launch_convert_stream_h2): within a
+                            // tile the positions only advance, into the head of the next tile's stream; a tile resets them
+    int c3;
 #ifdef NERF_STAMPS
     Stamper st;
 #endif
@@ -205,13 +206,15 @@ __device__ __forceinline__ unsigned lds_byte_addr(const void* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
 
+__device__ __forceinline__ void pipe_tile_start(PipeH& p) {
+    p.g2 = piece_src(p, 2) + 4096;      // (biased by half a wave's share: see consume_chunk)
+    p.g3 = piece_src(p, 3) + 4096;
+}
 __device__ __forceinline__ void pipe_start(PipeH& p) {
     static_assert(kRingH == 4, "ring slots are advanced with & 3");
     p.b = 0;
     p.fr = lds_byte_addr(p.lds) + p.lane * 16;
-    p.g2 = piece_src(p, 2 < p.n ? 2 : 2 % p.n) + 4096;      // (biased by half a wave's share: see consume_chunk)
-    p.c3 = 3 < p.n ? 3 : 3 % p.n;
-    p.g3 = piece_src(p, p.c3) + 4096;
+    pipe_tile_start(p);
 }
 template <int NSTEP, int NB, class Body>
 __device__ __forceinline__ void consume_chunk(PipeH& p, Frag4& cur, Body body) {
@@ -231,9 +234,7 @@ __device__ __forceinline__ void consume_chunk(PipeH& p, Frag4& cur, Body body) {
     p.b = b1;
     p.fr = fr_next;
     p.g2 = p.g3;
-    p.c3 = p.c3 + 1 == p.n ? 0 : p.c3 + 1;
-    // (one 64-bit add fewer with a carried per-lane base pointer measured 1 % SLOWER: code placement, guide rule 27)
-    p.g3 = p.stream + (size_t)(unsigned)p.c3 * kChunkBytes + (p.wave * 8192 + p.lane * 16 + 4096);
+    p.g3 += kChunkBytes;
 }
 
 // ---- per-point scaling and the fp16 split --------------------------------------------------

@@ -16,6 +16,7 @@ namespace nerf {
 // as `ds_read_b128` MFMA A-fragments (4 consecutive k-steps per lane per read).
 constexpr int kChunkFloats = 8192;
 constexpr int kChunkBytes = kChunkFloats * 4;
+constexpr int kStreamTailChunks = 3;      // the fp16-pair stream is followed by a copy of its first chunks (mlp_pair_common.h)
 constexpr int kGroupFloats = 256;            // 64 lanes x 4 k-steps
 constexpr int kBiasTileFloats = 32;          // [h(2)][16 accumulator registers]
 constexpr int kBiasLdsBytes = 20480;         // up to 160 bias / row-vector tiles
