@@ -380,7 +380,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
                 f32x16 x0, x1, dd;
                 float m_dd;
                 load_inputs<MODE, false, false>(a, pt, h, x0, x1, dd, &m_dd);
-                bound = fmaxf(bound, wave_max(m_dd));
+                bound = fmaxf(bound, wave_max_lds(m_dd));
             }
             else if ((a.skip_in_mask >> (l + 1)) & 1) bound = fmaxf(bound, m_pe);
             pd.t_out = pick_exponent(bound);

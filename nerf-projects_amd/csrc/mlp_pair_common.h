@@ -245,8 +245,26 @@ __device__ __forceinline__ int pick_exponent(float m) {
 }
 __device__ __forceinline__ float pow2f(int t) { return __builtin_ldexpf(1.0f, t); }
 
-// largest value over the wavefront, as a wave-uniform number (lives in an SGPR)
+// largest value over the wavefront (of non-negative values), as a wave-uniform number (lives in an SGPR). Six DPP steps
+// (within quads, half rows, rows, then row_bcast:15 / :31 into the last row) and a v_readlane instead of six
+// ds_bpermute round trips through the LDS crossbar with a wait each: non-negative floats order like their bit patterns.
 __device__ __forceinline__ float wave_max(float m) {
+    int v = __builtin_bit_cast(int, m);
+    auto fold = [&](auto ctrl, auto rows) {
+        const int t = __builtin_amdgcn_update_dpp(0, v, decltype(ctrl)::value, decltype(rows)::value, 0xf, false);
+        v = t > v ? t : v;
+    };
+    fold(PartTag<0xB1>{}, PartTag<0xf>{});     // quad_perm [1,0,3,2]
+    fold(PartTag<0x4E>{}, PartTag<0xf>{});     // quad_perm [2,3,0,1]
+    fold(PartTag<0x141>{}, PartTag<0xf>{});    // row_half_mirror
+    fold(PartTag<0x140>{}, PartTag<0xf>{});    // row_mirror: every lane of a row holds the row's maximum
+    fold(PartTag<0x142>{}, PartTag<0xa>{});    // row_bcast:15 into rows 1 and 3
+    fold(PartTag<0x143>{}, PartTag<0xc>{});    // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 63));
+}
+// (the same through the LDS crossbar: what make_pending uses while LDS reads of its own are in flight - with the DPP form
+// there hipcc moves the registers those reads are landing in, and tools/audit_lds_waits.py rejects the build)
+__device__ __forceinline__ float wave_max_lds(float m) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
