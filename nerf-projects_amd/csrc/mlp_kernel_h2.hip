@@ -158,11 +158,10 @@ __device__ __forceinline__ void convert_tile(XT& dst, const f32x16& src, Pending
     lds_tile_wait(b);
     convert_pairs<0>(dst, src, pd, b);
 }
-// tile 0 with its bias entries requested by make_pending, behind its scale-table read: the two LDS latencies of a layer
-// boundary overlap instead of adding up (-0.5 % per launch). Requested earlier still - before the layer's last chunk -
-// hipcc parks the in-flight destination registers in AGPRs (tools/audit_lds_waits.py rejects the build).
+// tile 0 with its bias entries already fetched by make_pending, together with its scale-table row: the two LDS latencies
+// of a layer boundary overlap instead of adding up (-0.5 % per launch). Requested earlier still - before the layer's last
+// chunk - hipcc parks the in-flight destination registers in AGPRs (tools/audit_lds_waits.py rejects the build).
 __device__ __forceinline__ void convert_tile0_with(XT& dst, const f32x16& src, Pending& pd, Tile16& b) {
-    lds_tile_wait(b);
     convert_pairs<0>(dst, src, pd, b);
 }
 
@@ -365,11 +364,15 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
         auto make_pending = [&](int l, float m_in, int t_in) {
             const bool is_feature = a.use_viewdirs && l == a.D;
             const unsigned baddr = bias0 + 128 * (is_feature ? 8 * a.D + 1 : 8 * l);
-            // the scale-table row and the bias entries of tile 0 in one go: five reads, one exposed LDS latency per layer
+            // the scale-table row and the bias entries of tile 0 in one go: five reads and ONE wait for all of them (one
+            // exposed LDS latency per layer instead of two). One statement: with reads still in flight across the
+            // arithmetic below, hipcc moved their destination registers whenever that arithmetic changed.
             f32x4 tab;
-            asm volatile("ds_read_b128 %0, %1" : "=&v"(tab) : "v"(lds_byte_addr(layer_tab + 4 * l)) : "memory");
-            bias0_req = lds_tile_issue(baddr);
-            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(tab)::"memory");
+            asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:16\n\t"
+                         "ds_read_b128 %3, %6 offset:32\n\tds_read_b128 %4, %6 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(tab), "=&v"(bias0_req.q[0]), "=&v"(bias0_req.q[1]), "=&v"(bias0_req.q[2]), "=&v"(bias0_req.q[3])
+                         : "v"(lds_byte_addr(layer_tab + 4 * l)), "v"(baddr)
+                         : "memory");
             pd.c = tab[0] * pow2f(-t_in);
             pd.floor = is_feature ? -__builtin_inff() : 0.0f;
             float bound = fmaf(tab[1], m_in, tab[2]) * 1.001f;
@@ -380,7 +383,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
                 f32x16 x0, x1, dd;
                 float m_dd;
                 load_inputs<MODE, false, false>(a, pt, h, x0, x1, dd, &m_dd);
-                bound = fmaxf(bound, wave_max_lds(m_dd));
+                bound = fmaxf(bound, wave_max(m_dd));
             }
             else if ((a.skip_in_mask >> (l + 1)) & 1) bound = fmaxf(bound, m_pe);
             pd.t_out = pick_exponent(bound);

@@ -262,13 +262,6 @@ __device__ __forceinline__ float wave_max(float m) {
     fold(PartTag<0x143>{}, PartTag<0xc>{});    // row_bcast:31 into rows 2 and 3
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 63));
 }
-// (the same through the LDS crossbar: what make_pending uses while LDS reads of its own are in flight - with the DPP form
-// there hipcc moves the registers those reads are landing in, and tools/audit_lds_waits.py rejects the build)
-__device__ __forceinline__ float wave_max_lds(float m) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
-}
 __device__ __forceinline__ float tile_absmax(const f32x16& v, float m) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(v[r]));
