@@ -80,7 +80,9 @@ void grad_batch_kernel(const GradBatch b) {
     auto step = [&](const f32x4u& a, const TnCols<NT>& b) {
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm) {
-            asum[tm] += a[tm];
+            // (opaque: as plain C++ hipcc gathers the eight k-steps' additions at the end of a group and keeps a copy of
+            // every A register for them - sixteen v_mov_b64 and their loads' waits in front of the group's first MFMA)
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(asum[tm]) : "v"(a[tm]));
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = mfma32(a[tm], b.v[tn], acc[tm][tn]);
         }
@@ -100,11 +102,16 @@ void grad_batch_kernel(const GradBatch b) {
         for (; s + 2 * kTnDepth <= n_steps; s += kTnDepth) {
 #pragma unroll
             for (int j = 0; j < kTnDepth; ++j) {
+                // pinned: the k-step's MFMAs, then its two loads and their address arithmetic - issued while the last of
+                // those MFMAs runs. Left alone hipcc hoists the loads, the bias sums and a copy of every operand register
+                // of all eight k-steps in front of the group's 128 MFMAs, ~110 instructions with an empty matrix pipe.
                 step(ra[j], rb[j]);
+                __builtin_amdgcn_sched_barrier(0);
                 ra[j] = *(const f32x4u*)pa;      // k-step s + kTnDepth + j, into the registers just consumed
                 rb[j] = tn_load_cols<NT>(pb);
                 pa += sa;
                 pb += sb;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
