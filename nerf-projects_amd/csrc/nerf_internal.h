@@ -230,6 +230,9 @@ struct GradJob {
     float* dbp;                   // [n_slices][Mo]
 };
 constexpr int kMaxGradJobs = 12;
+// points per slice are a multiple of this: whole 32-point tiles for the staged kernel, whole groups of k-steps (two points each,
+// eight in flight; 12 or 16 measured no faster) for the direct one - only the last slice of a pass ends in the predicated tail loop
+constexpr int kSlicePointQuantum = 96;
 struct GradBatch {
     int n, n_slices, accumulate;
     int64_t P, pts_per_slice;

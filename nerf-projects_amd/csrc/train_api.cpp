@@ -257,7 +257,7 @@ int grad_linear(const PackedNet& net, const LinearDesc& d, const float* dY, int 
                 const TnScratch& sc, hipStream_t s) {
     const int n_slices = pick_slices(P, d.out, d.in, sc.max_slices);
     int64_t pps = (P + n_slices - 1) / n_slices;
-    pps = (pps + 31) / 32 * 32;
+    pps = (pps + kSlicePointQuantum - 1) / kSlicePointQuantum * kSlicePointQuantum;
     // a trunk layer behind a skip reads cat[gamma(x), h] (nerf.py:79-80): its narrow columns come first; the view layer
     // reads cat[feature, gamma(d)] (nerf.py:93): last
     const bool trunk = &d >= &net.linears[0] && &d < &net.linears[0] + net.arch.D;
@@ -351,7 +351,7 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
         if (n_slices > cap) n_slices = (int)cap;
         if (n_slices < 1) n_slices = 1;
         int64_t pps = (ps.P + n_slices - 1) / n_slices;
-        pps = (pps + 31) / 32 * 32;
+        pps = (pps + kSlicePointQuantum - 1) / kSlicePointQuantum * kSlicePointQuantum;
         b->n_slices = n_slices;
         b->pts_per_slice = pps;
         b->P = ps.P;
