@@ -89,13 +89,19 @@ void nerf_ctx_destroy(nerf_ctx* ctx);
  *                         is equal or smaller than the fp32 MFMA chain's (rms <= 1.25x, max <= 2x, asserted by
  *                         tests/test_hip_parity.py::test_mlp_precisions_vs_fp64 incl. adversarial scalings), because
  *                         these errors are unbiased and far below the accumulated rounding of a 256-term fp32 sum.
- *                         Limits, also tested: a weight more than 2^12 below the largest of its LAYER, or an
- *                         activation more than 2^12 below the largest of its POINT, has a low half in the fp16
- *                         subnormal range (absolute resolution 2^-24 of the scaled unit) and keeps fewer than 24
- *                         bits; harmless when the large values feed the same outputs, a real loss when they do
- *                         not (a row of tiny weights next to a row of huge ones; a huge activation that the next
- *                         layer ignores). nerf_precision_status counts the loose-bound case; for such networks use
- *                         NERF_PRECISION_F32.
+ *                         Scale groups: a weight more than 2^12 below the largest of its LAYER, or an activation
+ *                         more than 2^12 below the largest of its POINT, has a low half in the fp16 subnormal
+ *                         range (absolute resolution 2^-24 of the scaled unit) and keeps fewer than 24 bits. So
+ *                         that hidden units of very different size do not meet in one group, the kernel evaluates
+ *                         a ROW-EQUALISED copy of the network, made at load time and after optimiser steps: unit j
+ *                         is scaled by 2^e_j to the largest row norm of its layer and column j of every layer that
+ *                         reads it by 2^-e_j - the same function exactly (ReLU commutes with positive factors, the
+ *                         factors are powers of two); nerf_get_weights returns the plain parameters. With it one
+ *                         row of a layer 2^20 larger than the others costs nothing, whether its output is used or
+ *                         not (tests/test_hip_parity.py::test_fp16_pair_rows_of_unequal_size). What remains is
+ *                         WITHIN a row (a weight 2^12 below the layer's largest matters only when the inputs of
+ *                         the large ones vanish) and within a point (units equal in norm but 2^12 apart on that
+ *                         point); nerf_precision_status counts the points whose scale bound was that loose.
  * A context starts in NERF_PRECISION_F16X2 (about 3x the frame rate of the fp32 chain).
  * Takes effect for the following calls on this context; weights loaded earlier stay valid. */
 #define NERF_PRECISION_F32 0
@@ -105,8 +111,8 @@ int nerf_get_precision(nerf_ctx* ctx);
 /* NERF_PRECISION_F16X2 chooses a layer's per-point output scale from an a-priori bound (largest row sum of |W| x
  * largest |input| + largest |bias|). A bound 2^12 or more above a point's real outputs starts to cost low-order
  * bits; each such (wavefront, layer) occurrence is counted, never silent. Synchronises the device; `reset` zeroes the
- * counter. 0 on every network trained or initialised like a NeRF; non-zero means: use NERF_PRECISION_F32 for these
- * weights (rows of large weights that cancel). */
+ * counter. 0 on every network trained or initialised like a NeRF; non-zero means: compare with NERF_PRECISION_F32 on
+ * these weights (rows of large weights that cancel). */
 int nerf_precision_status(nerf_ctx* ctx, int64_t* loose_bound_events, int reset);
 
 /* Weights ---------------------------------------------------------------------------

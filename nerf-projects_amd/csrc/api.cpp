@@ -29,13 +29,18 @@ using namespace nerf;
 
 namespace {
 
-int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net, int mode, hipStream_t s) {
+int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net_in, int mode, hipStream_t s) {
+    PackedNet& net = const_cast<PackedNet&>(net_in);   // (the lazily refreshed fp16-pair data are a cache of the parameters)
+    if (c->precision == NERF_PRECISION_F16X2 && net.h2_dirty) {
+        const int rc = refresh_h2(net, s);          // the weights have been trained since the last fp16-pair launch
+        if (rc != NERF_OK) return rc;
+    }
     a.stream = net.d_stream;
     a.stream_h2 = net.d_stream_h2;
     a.descale = net.d_descale;
     a.gain = net.d_gain;
     a.loose = c->d_loose;
-    a.bias = net.d_bias;
+    a.bias = c->precision == NERF_PRECISION_F16X2 ? net.d_bias_h2 : net.d_bias;
     a.n_chunks = net.n_chunks;
     a.n_bias_tiles = net.n_bias_tiles;
     a.D = net.arch.D;
@@ -89,6 +94,58 @@ int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net, int mode, hipStream
 }  // namespace
 
 namespace nerf {
+EqualiseRefs equalise_refs(const nerf_arch& a, const std::vector<LinearDesc>& linears) {
+    EqualiseRefs r{};
+    const int D = a.D, W = a.W;
+    r.n = (int)linears.size();
+    for (int k = 0; k < r.n; ++k) {
+        r.out[k] = linears[k].out;
+        r.in[k] = linears[k].in;
+        r.w_off[k] = (unsigned)linears[k].w_off;
+        r.b_off[k] = (unsigned)linears[k].b_off;
+        r.col_src[k] = -1;
+    }
+    auto reads = [&](int k, int src, int col0, int n) {
+        r.col_src[k] = src;
+        r.hid_col0[k] = col0;
+        r.n_hid[k] = n;
+    };
+    int n = 0;
+    for (int i = 0; i < D; ++i) {                      // trunk: relu(L_i h); a skip layer reads cat[gamma(x), h] (nerf.py:79-80)
+        r.scale_rows[i] = 1;
+        if (i > 0) reads(i, i - 1, linears[i].in - W, W);
+        r.order[n++] = i;
+    }
+    if (a.use_viewdirs) {                              // linears: ..., views (D), feature (D+1), alpha (D+2), rgb (D+3)
+        r.scale_rows[D + 1] = 1;                       // feature_linear: no ReLU, linear (nerf.py:89)
+        reads(D + 1, D - 1, 0, W);
+        reads(D + 2, D - 1, 0, W);                     // alpha_linear reads the trunk output; its row is an output
+        r.scale_rows[D] = 1;                           // views_linears[0] on cat[feature, gamma(d)] (nerf.py:93-98)
+        reads(D, D + 1, 0, W);
+        reads(D + 3, D, 0, linears[D].out);            // rgb_linear
+        r.order[n++] = D + 1;
+        r.order[n++] = D + 2;
+        r.order[n++] = D;
+        r.order[n++] = D + 3;
+    } else {                                           // linears: ..., views (D, unused by forward), output (D+1)
+        reads(D + 1, D - 1, 0, W);
+        r.order[n++] = D;
+        r.order[n++] = D + 1;
+    }
+    return r;
+}
+
+int refresh_h2(PackedNet& net, hipStream_t s) {
+    HIP_TRY(launch_equalise_rows(net.d_params, equalise_refs(net.arch, net.linears), net.d_params_eq, s));
+    HIP_TRY(launch_gather(net.d_params_eq, net.train.d_stream_table, (int64_t)net.stream_table.size(), net.d_stream_eq, s));
+    HIP_TRY(launch_gather(net.d_params_eq, net.train.d_bias_table, (int64_t)net.bias_table.size(), net.d_bias_h2, s));
+    HIP_TRY(launch_convert_stream_h2(net.d_stream_eq, net.d_chunk_layer, net.n_chunks, net.d_chunk_max, net.d_stream_h2,
+                                     net.d_descale, s));
+    HIP_TRY(launch_layer_gains(net.d_params_eq, gain_refs(net.arch, net.linears), net.d_gain, s));
+    net.h2_dirty = false;
+    return NERF_OK;
+}
+
 GainRefs gain_refs(const nerf_arch& a, const std::vector<LinearDesc>& linears) {
     GainRefs r{};
     r.n = a.use_viewdirs ? a.D + 1 : a.D;
@@ -109,7 +166,7 @@ void free_net(PackedNet& n) {
     for (void* p : {(void*)n.d_stream, (void*)n.d_bias, (void*)n.d_params, (void*)n.train.d_grad, (void*)n.train.d_m,
                     (void*)n.train.d_v, (void*)n.train.d_wt, (void*)n.train.d_stream_table,
                     (void*)n.train.d_bias_table, (void*)n.train.d_bwd_table, (void*)n.train.d_stream_bwd, (void*)n.d_stream_h2, (void*)n.d_descale, (void*)n.d_chunk_layer,
-                    (void*)n.d_chunk_max, (void*)n.d_gain})
+                    (void*)n.d_chunk_max, (void*)n.d_gain, (void*)n.d_params_eq, (void*)n.d_stream_eq, (void*)n.d_bias_h2})
         if (p) (void)hipFree(p);
     n = PackedNet{};
 }
@@ -338,11 +395,23 @@ int nerf_load_weights(nerf_ctx* c, int slot, const nerf_arch* arch, const float*
     if (e == hipSuccess) e = hipMalloc((void**)&net.d_chunk_max, (size_t)nc * sizeof(float));
     if (e == hipSuccess)
         e = hipMemcpy(net.d_chunk_layer, layer_of.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = launch_convert_stream_h2(net.d_stream, net.d_chunk_layer, nc, net.d_chunk_max, net.d_stream_h2,
-                                     net.d_descale, nullptr);
     if (e == hipSuccess) e = hipMalloc((void**)&net.d_gain, 2 * (kMaxDepth + 2) * sizeof(float));
-    if (e == hipSuccess) e = launch_layer_gains(net.d_params, gain_refs(*arch, net.linears), net.d_gain, nullptr);
+    // the row-equalised copy the fp16-pair kernel evaluates, and the index tables that cut streams out of parameters
+    if (e == hipSuccess) e = hipMalloc((void**)&net.d_params_eq, net.n_params * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&net.d_stream_eq, (size_t)nc * kChunkBytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&net.d_bias_h2, (size_t)nbt * kBiasTileFloats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&net.train.d_stream_table, net.stream_table.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&net.train.d_bias_table, net.bias_table.size() * sizeof(int));
+    if (e == hipSuccess)
+        e = hipMemcpy(net.train.d_stream_table, net.stream_table.data(), net.stream_table.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(net.train.d_bias_table, net.bias_table.data(), net.bias_table.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        net.arch = *arch;           // (refresh_h2 reads these; set again below with the rest)
+        net.n_chunks = nc;
+        net.n_bias_tiles = nbt;
+        if (refresh_h2(net, nullptr) != NERF_OK) return NERF_E_HIP;
+    }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         set_error("uploading packed weights failed: %s", hipGetErrorString(e));

@@ -656,6 +656,63 @@ __global__ __launch_bounds__(256) void layer_gain_kernel(const float* params, co
     }
 }
 
+// Row equalisation (PackedNet::d_params_eq). ReLU commutes with positive factors and feature_linear is linear, so scaling
+// hidden unit j of a layer by s_j = 2^e_j and dividing column j of every layer that reads it by s_j leaves the network's
+// function unchanged - exactly, the factors being powers of two - while every row of a layer gets the same norm
+// binade. The fp16-pair kernel scales a LAYER's weights by one factor and a POINT's activations by one factor: a unit
+// with weights 2^13 below another's used to lose its low halves, and its small outputs theirs; now neither happens.
+// One workgroup walks the layers in order (a layer's column factors are its producer's row factors); thread = row.
+__global__ __launch_bounds__(256) void equalise_rows_kernel(const float* params, const EqualiseRefs r, float* out) {
+    __shared__ int expo[kMaxLinears][256];    // e_j of the scaled linears
+    __shared__ int red[4];
+    const int j = threadIdx.x;
+    for (int idx = 0; idx < r.n; ++idx) {
+        const int k = r.order[idx];
+        const int n_out = r.out[k], n_in = r.in[k], src = r.col_src[k], c0 = r.hid_col0[k], c1 = c0 + r.n_hid[k];
+        const float* w = params + r.w_off[k] + (size_t)j * n_in;
+        float* o = out + r.w_off[k] + (size_t)j * n_in;
+        double m2 = 0.0;                                    // row norm^2 (double: |w| up to FLT_MAX squares without overflow)
+        if (j < n_out)
+            for (int c = 0; c < n_in; ++c) {
+                float v = w[c];
+                if (src >= 0 && c >= c0 && c < c1) v = __builtin_ldexpf(v, -expo[src][c - c0]);
+                o[c] = v;                                   // column factors applied; the row factor follows
+                m2 += (double)v * (double)v;
+            }
+        int e = 0;
+        if (r.scale_rows[k]) {
+            // binade of the largest row NORM of the layer: with inputs of comparable size a unit's output scales with
+            // the l2 norm of its row (the largest |w| misjudges a row that copies one input next to rows that sum 256)
+            // - rows of zeros and non-finite rows keep factor 1
+            const bool ok = j < n_out && m2 > 0.0 && m2 < (double)__builtin_inff() * (double)__builtin_inff();
+            int ej = -1000;
+            if (ok) (void)frexp(sqrt(m2), &ej);
+            int top = ej;
+            for (int o2 = 32; o2 > 0; o2 >>= 1) top = max(top, __shfl_xor(top, o2));
+            if ((j & 63) == 0) red[j >> 6] = top;
+            __syncthreads();
+            top = max(max(red[0], red[1]), max(red[2], red[3]));
+            e = ok ? top - ej : 0;
+            e = e > 30 ? 30 : e;                            // a unit 2^30 below the largest is not brought all the way up
+        }
+        expo[k][j] = e;
+        if (j < n_out) {
+            if (e != 0)
+                for (int c = 0; c < n_in; ++c) o[c] = __builtin_ldexpf(o[c], e);
+            out[r.b_off[k] + j] = __builtin_ldexpf(params[r.b_off[k] + j], e);
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_equalise_rows(const float* params, const EqualiseRefs& refs, float* params_eq, hipStream_t s) {
+    if (refs.n <= 0 || refs.n > kMaxLinears) return hipErrorInvalidValue;
+    for (int k = 0; k < refs.n; ++k)
+        if (refs.out[k] > 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(equalise_rows_kernel, dim3(1), dim3(256), 0, s, params, refs, params_eq);
+    return hipGetLastError();
+}
+
 hipError_t launch_layer_gains(const float* params, const GainRefs& refs, float* gain, hipStream_t s) {
     if (refs.n <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(gain, 0, 2 * (size_t)refs.n * sizeof(float), s);

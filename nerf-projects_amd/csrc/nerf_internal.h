@@ -83,6 +83,13 @@ struct PackedNet {
     int* d_chunk_layer = nullptr;
     float* d_chunk_max = nullptr;
     float* d_gain = nullptr;     // per layer [max row sum of |W|, max |b|]: bounds a layer's outputs from its inputs
+    // What the fp16-pair kernel evaluates is a ROW-EQUALISED copy of the parameters (launch_equalise_rows): the same function,
+    // every hidden unit scaled by a power of two that brings its weight row to the layer's largest row, the factor undone in
+    // the columns of the layers that read the unit. The stream, the bias block and the gains of that kernel come from it.
+    float* d_params_eq = nullptr;
+    float* d_stream_eq = nullptr;   // fp32 stream of the equalised parameters (input of the fp16-pair conversion)
+    float* d_bias_h2 = nullptr;     // bias block of the equalised parameters
+    bool h2_dirty = false;          // the master parameters changed (optimiser step): refresh before the next fp16-pair launch
     int n_chunks = 0;
     int n_bias_tiles = 0;
     uint32_t skip_in_mask = 0;   // bit i: trunk layer i reads [input_pts, h]
@@ -173,6 +180,21 @@ struct GainRefs {
 };
 GainRefs gain_refs(const nerf_arch& arch, const std::vector<LinearDesc>& linears);
 hipError_t launch_layer_gains(const float* params, const GainRefs& refs, float* gain, hipStream_t s);
+// Row equalisation of the hidden layers (see PackedNet::d_params_eq). Linears are processed in `order`; linear k has its
+// rows scaled if scale_rows[k]; the `n_hid[k]` columns from `hid_col0[k]` on are divided by the row scales of linear
+// col_src[k] (-1: none).
+constexpr int kMaxLinears = 16;
+struct EqualiseRefs {
+    int n;
+    int order[kMaxLinears];
+    int out[kMaxLinears], in[kMaxLinears];
+    unsigned w_off[kMaxLinears], b_off[kMaxLinears];
+    int scale_rows[kMaxLinears], col_src[kMaxLinears], hid_col0[kMaxLinears], n_hid[kMaxLinears];
+};
+hipError_t launch_equalise_rows(const float* params, const EqualiseRefs& refs, float* params_eq, hipStream_t s);
+struct PackedNet;
+// everything the fp16-pair kernel reads, rebuilt from the master parameters (api.cpp; at load and, lazily, after training steps)
+int refresh_h2(PackedNet& net, hipStream_t s);
 hipError_t launch_convert_stream_h2(const float* stream, const int* chunk_layer, int n_chunks, float* chunk_max,
                                     uint32_t* out, float* descale, hipStream_t s);
 hipError_t launch_embed(const float* x, int64_t n, int multires, float* out, hipStream_t s);

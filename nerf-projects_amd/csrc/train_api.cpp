@@ -25,12 +25,7 @@ int ensure_train_state(nerf_ctx* c, PackedNet& net) {
     HIP_TRY(hipMemset(t.d_grad, 0, nb));
     HIP_TRY(hipMemset(t.d_m, 0, nb));
     HIP_TRY(hipMemset(t.d_v, 0, nb));
-    HIP_TRY(hipMalloc((void**)&t.d_stream_table, net.stream_table.size() * sizeof(int)));
-    HIP_TRY(hipMalloc((void**)&t.d_bias_table, net.bias_table.size() * sizeof(int)));
-    HIP_TRY(hipMemcpy(t.d_stream_table, net.stream_table.data(), net.stream_table.size() * sizeof(int),
-                      hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(t.d_bias_table, net.bias_table.data(), net.bias_table.size() * sizeof(int),
-                      hipMemcpyHostToDevice));
+    // (d_stream_table / d_bias_table: uploaded by nerf_load_weights, which needs them for the fp16-pair stream)
     if (!net.bwd_table.empty()) {
         HIP_TRY(hipMalloc((void**)&t.d_bwd_table, net.bwd_table.size() * sizeof(int)));
         HIP_TRY(hipMemcpy(t.d_bwd_table, net.bwd_table.data(), net.bwd_table.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -50,9 +45,7 @@ int refresh_derived(PackedNet& net, hipStream_t s) {
             HIP_TRY(launch_transpose(net.d_params + d.w_off, d.out, d.in, net.train.d_wt + d.w_off, s));
     HIP_TRY(launch_gather(net.d_params, net.train.d_stream_table, (int64_t)net.stream_table.size(), net.d_stream, s));
     HIP_TRY(launch_gather(net.d_params, net.train.d_bias_table, (int64_t)net.bias_table.size(), net.d_bias, s));
-    HIP_TRY(launch_convert_stream_h2(net.d_stream, net.d_chunk_layer, net.n_chunks, net.d_chunk_max, net.d_stream_h2,
-                                     net.d_descale, s));
-    HIP_TRY(launch_layer_gains(net.d_params, gain_refs(net.arch, net.linears), net.d_gain, s));
+    net.h2_dirty = true;      // the fp16-pair kernel's stream, bias block and gains follow at its next launch (refresh_h2)
     if (net.train.d_stream_bwd)
         HIP_TRY(launch_gather(net.d_params, net.train.d_bwd_table, (int64_t)net.bwd_table.size(), net.train.d_stream_bwd, s));
     return NERF_OK;
