@@ -36,23 +36,21 @@ __device__ __forceinline__ f32x16 mma(const f32x4& a, const u32x4& b, f32x16 c) 
 // MFMA K (0..5) of a step, small terms first
 template <int K, bool FIRST>
 __device__ __forceinline__ void mma_one(f32x16& acc, const Frag4& f, const XT& x) {
-    if constexpr (K == 0) {
-        if constexpr (FIRST) {
-            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            acc = mma(f.q[1], x.hi[0], zero);
-        } else {
-            acc = mma(f.q[1], x.hi[0], acc);
-        }
-    } else if constexpr (K == 1) {
-        acc = mma(f.q[0], x.lo[0], acc);
-    } else if constexpr (K == 2) {
-        acc = mma(f.q[0], x.hi[0], acc);
-    } else if constexpr (K == 3) {
-        acc = mma(f.q[3], x.hi[1], acc);
-    } else if constexpr (K == 4) {
-        acc = mma(f.q[2], x.lo[1], acc);
+#ifdef NERF_MMA_SHARED_OPERANDS
+    // neighbours share an operand: (q0,lo0) (q0,hi0) (q1,hi0) | (q3,hi1) (q2,hi1) (q2,lo1)
+    constexpr int A[6] = {0, 0, 1, 3, 2, 2};
+    constexpr bool LO[6] = {true, false, false, false, false, true};
+#else
+    constexpr int A[6] = {1, 0, 0, 3, 2, 2};
+    constexpr bool LO[6] = {false, true, false, false, true, false};
+#endif
+    constexpr int s = K / 3;
+    const u32x4& b = LO[K] ? x.lo[s] : x.hi[s];
+    if constexpr (K == 0 && FIRST) {
+        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc = mma(f.q[A[K]], b, zero);
     } else {
-        acc = mma(f.q[2], x.hi[1], acc);
+        acc = mma(f.q[A[K]], b, acc);
     }
 }
 
