@@ -166,7 +166,8 @@ void free_net(PackedNet& n) {
     for (void* p : {(void*)n.d_stream, (void*)n.d_bias, (void*)n.d_params, (void*)n.train.d_grad, (void*)n.train.d_m,
                     (void*)n.train.d_v, (void*)n.train.d_wt, (void*)n.train.d_stream_table,
                     (void*)n.train.d_bias_table, (void*)n.train.d_bwd_table, (void*)n.train.d_stream_bwd, (void*)n.d_stream_h2, (void*)n.d_descale, (void*)n.d_chunk_layer,
-                    (void*)n.d_chunk_max, (void*)n.d_gain, (void*)n.d_params_eq, (void*)n.d_stream_eq, (void*)n.d_bias_h2})
+                    (void*)n.d_chunk_max, (void*)n.d_gain, (void*)n.d_params_eq, (void*)n.d_stream_eq, (void*)n.d_bias_h2,
+                    (void*)n.train.d_stream_h2, (void*)n.train.d_descale, (void*)n.train.d_gain})
         if (p) (void)hipFree(p);
     n = PackedNet{};
 }

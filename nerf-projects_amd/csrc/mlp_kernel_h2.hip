@@ -121,9 +121,42 @@ struct Pending {
     int t_out;
     unsigned bias_addr;    // LDS address of this half-wave's bias entries of tile 0 (tile t: + 128 t)
     float m;       // running max |y|
+    float* keep_base;      // STORE kernels: the buffer that keeps this layer's activations for the backward pass ...
+    unsigned keep_off;     // ... and this lane's BYTE offset of (its point, feature 4 h) in it
+    f32x2 even;            // (convert_pair: the even pair of a register quad, until the odd one completes the 16 bytes)
 };
 
-template <int P>
+// Training forward (STORE kernels): register pair P of tile T of the pending layer - features 32 T + 8 (P/2) + 2 (P%2) + 4 h
+// + {0, 1} of this lane's point, true units - goes to the row-major [points, channels] buffer autograd would keep
+// (MlpStore; the layout of mlp_kernel.hip's store_tile_at). Wave-uniform base, one 32-bit byte offset per lane (the
+// launcher bounds the buffers), the rest an immediate: ONE instruction in a step whose issue slots are nearly all taken.
+// Lanes past the end recompute the last point and write the same values to the same address.
+template <int T, int P>
+__device__ __forceinline__ void keep_pair(const Pending& pd, float y0, float y1) {
+    const f32x2 v = {y0, y1};
+    asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3"
+                 :
+                 : "v"(pd.keep_off), "v"(v), "s"(pd.keep_base), "n"((32 * T + 8 * (P >> 1) + 2 * (P & 1)) * 4)
+                 : "memory");
+}
+// two pairs (a register quad: four consecutive features) in one 16-byte store: half the instructions and half the write
+// requests of keep_pair
+template <int T, int Q>
+__device__ __forceinline__ void keep_pairs(const Pending& pd, const f32x2& even, float y0, float y1) {
+    const f32x4 v = {even[0], even[1], y0, y1};
+    // (s_nop 1: a store of more than 8 bytes reads its data registers late - two wait states before a vector instruction
+    // may overwrite them on gfx950; hipcc's hazard recogniser does not look inside inline asm)
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1"
+                 :
+                 : "v"(pd.keep_off), "v"(v), "s"(pd.keep_base), "n"((32 * T + 8 * Q) * 4)
+                 : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ void keep_quad(float* base, unsigned off, const f32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base), "n"(IMM) : "memory");
+}
+
+template <int P, bool STORE = false, int T = 0>
 __device__ __forceinline__ void convert_pair(XT& dst, const f32x16& src, Pending& pd, const f32x2& b) {
 #ifdef NERF_ABLATE_CONV
     if (P == 0) dst.hi[0][0] = __float_as_uint(src[0] + b[0]);
@@ -131,6 +164,10 @@ __device__ __forceinline__ void convert_pair(XT& dst, const f32x16& src, Pending
 #endif
     const float y0 = fmaxf(fmaf(src[2 * P], pd.c, b[0]), pd.floor);
     const float y1 = fmaxf(fmaf(src[2 * P + 1], pd.c, b[1]), pd.floor);
+    if constexpr (STORE) {
+        if constexpr ((P & 1) == 0) pd.even = f32x2{y0, y1};
+        else keep_pairs<T, (P >> 1)>(pd, pd.even, y0, y1);
+    }
     pd.m = fmaxf(fmaxf(pd.m, fabsf(y0)), fabsf(y1));
     const float a0 = y0 * pd.sc, a1 = y1 * pd.sc;
     const unsigned hi = __builtin_bit_cast(unsigned, round_pair(a0, a1));
@@ -143,24 +180,25 @@ __device__ __forceinline__ void convert_pair(XT& dst, const f32x16& src, Pending
 }
 
 // a whole tile at once (not hidden: tile 0 at the start of a layer)
-template <int P>
+template <int P, bool STORE = false, int T = 0>
 __device__ __forceinline__ void convert_pairs(XT& dst, const f32x16& src, Pending& pd, const Tile16& b) {
     if constexpr (P < 8) {
-        convert_pair<P>(dst, src, pd, f32x2{b.q[P >> 1][2 * (P & 1)], b.q[P >> 1][2 * (P & 1) + 1]});
-        convert_pairs<P + 1>(dst, src, pd, b);
+        convert_pair<P, STORE, T>(dst, src, pd, f32x2{b.q[P >> 1][2 * (P & 1)], b.q[P >> 1][2 * (P & 1) + 1]});
+        convert_pairs<P + 1, STORE, T>(dst, src, pd, b);
     }
 }
-template <int T>
+template <int T, bool STORE = false>
 __device__ __forceinline__ void convert_tile(XT& dst, const f32x16& src, Pending& pd) {
     Tile16 b = lds_tile_issue(pd.bias_addr + 128 * T);
     lds_tile_wait(b);
-    convert_pairs<0>(dst, src, pd, b);
+    convert_pairs<0, STORE, T>(dst, src, pd, b);
 }
 // tile 0 with its bias entries already fetched by make_pending, together with its scale-table row: the two LDS latencies
 // of a layer boundary overlap instead of adding up (-0.5 % per launch). Requested earlier still - before the layer's last
 // chunk - hipcc parks the in-flight destination registers in AGPRs (tools/audit_lds_waits.py rejects the build).
+template <bool STORE = false>
 __device__ __forceinline__ void convert_tile0_with(XT& dst, const f32x16& src, Pending& pd, Tile16& b) {
-    convert_pairs<0>(dst, src, pd, b);
+    convert_pairs<0, STORE, 0>(dst, src, pd, b);
 }
 
 // convert_pair cut into the three slices that ride behind MFMAs 1, 2 and 3 of a step
@@ -184,19 +222,25 @@ __device__ __forceinline__ void conv_slice1(ConvTmp& t, Pending& pd) {
 // chunk kinds (group order: pack_weights.cpp, each unit of four groups re-cut into [k-slice][hi|lo] by
 // convert_stream_h2 below). CONV >= 0: while the chunk runs, step s converts register pair s of pending tile CONV;
 // its two bias entries are requested one step earlier.
-template <int CONV, bool FIRST>
+template <int CONV, bool FIRST, bool STORE = false>
 __device__ __forceinline__ void chunk_ktile8(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x, XT (&hid)[8],
                                              const f32x16 (&pend)[8], Pending& pd) {
     constexpr int C0 = CONV < 0 ? 0 : CONV;
     f32x2 r;
     ConvTmp t;
+    f32x2 even;     // STORE: the even pair of a register quad waits a step for the odd one
     if constexpr (CONV >= 0) r = lds_pair_issue<128 * C0>(pd.bias_addr);
     consume_chunk<8, (CONV >= 0 ? 1 : 0)>(p, cur, [&](auto tag, auto part, const Frag4& f) {
         constexpr int s = decltype(tag)::value, pt = decltype(part)::value;
         if constexpr (pt < 6) mma_one<pt, FIRST>(acc[s], f, x);
         else if constexpr (CONV >= 0) {
-            if constexpr (pt == 11) conv_slice0<s>(t, pend[C0], pd, r);
-            else if constexpr (pt == 12) conv_slice1(t, pd);
+            if constexpr (pt == 11) {
+                conv_slice0<s>(t, pend[C0], pd, r);
+                if constexpr (STORE) {
+                    if constexpr ((s & 1) == 0) even = f32x2{t.y0, t.y1};
+                    else keep_pairs<C0, (s >> 1)>(pd, even, t.y0, t.y1);
+                }
+            } else if constexpr (pt == 12) conv_slice1(t, pd);
             else if constexpr (pt == 13) conv_slice2<s>(hid[C0], t);
             else if constexpr (pt == 14 && s < 7) r = lds_pair_issue<128 * C0 + 8 * (s + 1)>(pd.bias_addr);
         }
@@ -208,12 +252,13 @@ __device__ __forceinline__ void chunk_ktile4(PipeH& p, Frag4& cur, f32x16 (&acc)
         if constexpr (pt < 6) mma_one<pt, false>(acc[s], f, x);
     });
 }
-template <int CONV, bool FIRST>
+template <int CONV, bool FIRST, bool STORE = false>
 __device__ __forceinline__ void chunk_pair4(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x0, const XT& x1,
                                             XT (&hid)[8], const f32x16 (&pend)[8], Pending& pd) {
     constexpr int C0 = CONV < 0 ? 0 : CONV;
     f32x2 r0, r1;
     ConvTmp t0, t1;
+    f32x2 even0, even1;
     if constexpr (CONV >= 0) {
         r0 = lds_pair_issue<128 * C0>(pd.bias_addr);
         r1 = lds_pair_issue<128 * (C0 + 1)>(pd.bias_addr);
@@ -227,6 +272,15 @@ __device__ __forceinline__ void chunk_pair4(PipeH& p, Frag4& cur, f32x16 (&acc)[
             if constexpr (pt == 11) {
                 conv_slice0<s>(t0, pend[C0], pd, r0);
                 conv_slice0<s>(t1, pend[C0 + 1], pd, r1);
+                if constexpr (STORE) {
+                    if constexpr ((s & 1) == 0) {
+                        even0 = f32x2{t0.y0, t0.y1};
+                        even1 = f32x2{t1.y0, t1.y1};
+                    } else {
+                        keep_pairs<C0, (s >> 1)>(pd, even0, t0.y0, t0.y1);
+                        keep_pairs<C0 + 1, (s >> 1)>(pd, even1, t1.y0, t1.y1);
+                    }
+                }
             } else if constexpr (pt == 12) {
                 conv_slice1(t0, pd);
                 conv_slice1(t1, pd);
@@ -262,6 +316,16 @@ __device__ __forceinline__ void finish_views(f32x16 (&y)[4], const f32x16 (&acc)
     }
 }
 
+// STORE: the view layer's four output tiles, 16 bytes per instruction
+template <int I>
+__device__ __forceinline__ void keep_tiles4(float* base, unsigned off, const f32x16 (&y)[4]) {
+    if constexpr (I < 16) {
+        constexpr int t = I >> 2, q = I & 3;
+        keep_quad<(32 * t + 8 * q) * 4>(base, off, f32x4{y[t][4 * q], y[t][4 * q + 1], y[t][4 * q + 2], y[t][4 * q + 3]});
+        keep_tiles4<I + 1>(base, off, y);
+    }
+}
+
 // One output row of a Linear over 4 fp32 activation tiles (weights per register in the bias block)
 __device__ __forceinline__ float row_dot4(const f32x16 (&x)[4], unsigned w_addr) {
     float s0 = 0.0f, s1 = 0.0f;
@@ -282,7 +346,10 @@ __device__ __forceinline__ float row_dot4(const f32x16 (&x)[4], unsigned w_addr)
 }
 
 // ---- the kernel -------------------------------------------------------------------------
-template <int MODE>
+// STORE: the training forward pass - also writes what autograd would keep (MlpLaunch::st: every trunk layer's post-ReLU
+// output, the feature vector, the view layer's output), each value as it leaves conv_slice0 / convert_pair / finish_views.
+// The stream it is given is the PLAIN network's (no row equalisation): the kept activations are the reference's.
+template <int MODE, bool STORE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void nerf_mlp_h2_kernel(const MlpLaunch a) {
     // The ring is the dynamic LDS allocation; the bias block and the small per-layer tables are static.
@@ -388,6 +455,10 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             pd.sc = pow2f(pd.t_out);
             pd.bias_addr = baddr;
             pd.m = 0.0f;
+            if constexpr (STORE) {
+                pd.keep_base = is_feature ? a.st.feat : a.st.h[l];
+                pd.keep_off = 4u * ((unsigned)pt * (unsigned)(is_feature ? a.st.feat_ld : a.st.h_ld[l]) + 4u * (unsigned)h);
+            }
         };
         // all 8 tiles of the pending layer are converted: its true output range
         auto close_pending = [&]() {
@@ -406,14 +477,14 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
         // trunk layers 1..D-1, then (with viewdirs) feature_linear as layer D without ReLU. Layer l accumulates
         // into `out` while the pending layer l-1 is converted out of `pend`.
         auto layer_pass = [&](f32x16 (&pend)[8], f32x16 (&out)[8], int l) {
-            convert_tile0_with(hid[0], pend[0], pd, bias0_req);
-            chunk_ktile8<1, true>(pipe, cur, out, hid[0], hid, pend, pd);
-            chunk_ktile8<2, false>(pipe, cur, out, hid[1], hid, pend, pd);
-            chunk_ktile8<3, false>(pipe, cur, out, hid[2], hid, pend, pd);
-            chunk_ktile8<4, false>(pipe, cur, out, hid[3], hid, pend, pd);
-            chunk_ktile8<5, false>(pipe, cur, out, hid[4], hid, pend, pd);
-            chunk_ktile8<6, false>(pipe, cur, out, hid[5], hid, pend, pd);
-            chunk_ktile8<7, false>(pipe, cur, out, hid[6], hid, pend, pd);
+            convert_tile0_with<STORE>(hid[0], pend[0], pd, bias0_req);
+            chunk_ktile8<1, true, STORE>(pipe, cur, out, hid[0], hid, pend, pd);
+            chunk_ktile8<2, false, STORE>(pipe, cur, out, hid[1], hid, pend, pd);
+            chunk_ktile8<3, false, STORE>(pipe, cur, out, hid[2], hid, pend, pd);
+            chunk_ktile8<4, false, STORE>(pipe, cur, out, hid[3], hid, pend, pd);
+            chunk_ktile8<5, false, STORE>(pipe, cur, out, hid[4], hid, pend, pd);
+            chunk_ktile8<6, false, STORE>(pipe, cur, out, hid[5], hid, pend, pd);
+            chunk_ktile8<7, false, STORE>(pipe, cur, out, hid[6], hid, pend, pd);
             chunk_ktile8<-1, false>(pipe, cur, out, hid[7], hid, pend, pd);
             close_pending();
             const int t_in = pd.t_out;
@@ -455,11 +526,11 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
         if (a.use_viewdirs) {
             // views_linears[0] on cat[feature, gamma(dir)] (nerf.py:93-98): 4 output tiles; the pending layer is
             // feature_linear
-            convert_tile0_with(hid[0], accA[0], pd, bias0_req);
-            convert_tile<1>(hid[1], accA[1], pd);
-            chunk_pair4<2, true>(pipe, cur, accB, hid[0], hid[1], hid, accA, pd);
-            chunk_pair4<4, false>(pipe, cur, accB, hid[2], hid[3], hid, accA, pd);
-            chunk_pair4<6, false>(pipe, cur, accB, hid[4], hid[5], hid, accA, pd);
+            convert_tile0_with<STORE>(hid[0], accA[0], pd, bias0_req);
+            convert_tile<1, STORE>(hid[1], accA[1], pd);
+            chunk_pair4<2, true, STORE>(pipe, cur, accB, hid[0], hid[1], hid, accA, pd);
+            chunk_pair4<4, false, STORE>(pipe, cur, accB, hid[2], hid[3], hid, accA, pd);
+            chunk_pair4<6, false, STORE>(pipe, cur, accB, hid[4], hid[5], hid, accA, pd);
             chunk_pair4<-1, false>(pipe, cur, accB, hid[6], hid[7], hid, accA, pd);
             close_pending();
             XT xd;
@@ -476,6 +547,10 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             }
             f32x16 y[4];
             finish_views(y, accB, bias0 + 128 * (8 * a.D + 9), lds_scalar(layer_tab + 4 * (a.D + 1)) * pow2f(-pd.t_out));
+            if constexpr (STORE) {
+                const unsigned off = 4u * ((unsigned)pt * (unsigned)a.st.hv_ld + 4u * (unsigned)h);
+                keep_tiles4<0>(a.st.hv, off, y);
+            }
             // rgb_linear (nerf.py:101): three rows over the 128-wide view layer
             const float* rb = bias_lds + (8 * a.D + 13) * 32;
             const float r0 = row_dot4(y, bias0 + 128 * (8 * a.D + 22)) + lds_scalar(rb);
@@ -544,6 +619,27 @@ hipError_t launch_mlp_h2(const MlpLaunch& a, int mode, hipStream_t s) {
     const size_t lds = kRingH * kChunkBytes;   // + 20.5 KiB static (bias block, layer scales)
     static bool raised[64][3] = {};
     if (mode < 0 || mode > 2) return hipErrorInvalidValue;
+    if (a.store) {
+        // training forward: ray records, a view-dependent network, buffers the one-instruction stores can address
+        // (16-byte aligned rows, byte offsets below 2^32)
+        if (mode != kInputRays || !a.use_viewdirs) return hipErrorInvalidValue;
+        auto ok = [&](const float* b, int ld) {
+            return b != nullptr && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0 &&
+                   (uint64_t)a.n_points * (uint64_t)ld * 4u < ((uint64_t)1 << 32);
+        };
+        bool rows_ok = ok(a.st.feat, a.st.feat_ld) && ok(a.st.hv, a.st.hv_ld);
+        for (int i = 0; i < a.D; ++i) rows_ok = rows_ok && ok(a.st.h[i], a.st.h_ld[i]);
+        if (!rows_ok) return hipErrorInvalidValue;
+        static bool raised_store[64] = {};
+        if (!raised_store[dev]) {
+            e = hipFuncSetAttribute((const void*)nerf_mlp_h2_kernel<kInputRays, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            raised_store[dev] = true;
+        }
+        hipLaunchKernelGGL((nerf_mlp_h2_kernel<kInputRays, true>), grid, block, lds, s, a);
+        return hipGetLastError();
+    }
     if (!raised[dev][mode]) {
         const void* fn = mode == kInputEmbedded ? (const void*)nerf_mlp_h2_kernel<kInputEmbedded>
                          : mode == kInputPoints ? (const void*)nerf_mlp_h2_kernel<kInputPoints>

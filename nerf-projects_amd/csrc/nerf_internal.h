@@ -63,6 +63,12 @@ struct TrainState {
     float* d_stream_bwd = nullptr;   // transposed-weight stream of the fused backward-data kernel
     int n_chunks_bwd = 0;
     bool grads_valid = false;
+    // fp16-pair stream of the PLAIN parameters (no row equalisation: the training forward pass keeps its activations for
+    // the backward pass, so they have to be the network's own), its layer scales and output bounds; made on demand
+    uint32_t* d_stream_h2 = nullptr;
+    float* d_descale = nullptr;
+    float* d_gain = nullptr;
+    bool h2_dirty = true;
 };
 
 struct PackedNet {

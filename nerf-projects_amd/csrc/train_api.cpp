@@ -46,6 +46,7 @@ int refresh_derived(PackedNet& net, hipStream_t s) {
     HIP_TRY(launch_gather(net.d_params, net.train.d_stream_table, (int64_t)net.stream_table.size(), net.d_stream, s));
     HIP_TRY(launch_gather(net.d_params, net.train.d_bias_table, (int64_t)net.bias_table.size(), net.d_bias, s));
     net.h2_dirty = true;      // the fp16-pair kernel's stream, bias block and gains follow at its next launch (refresh_h2)
+    net.train.h2_dirty = true;    // and so does the training forward pass's fp16-pair stream (forward_pass_fused)
     if (net.train.d_stream_bwd)
         HIP_TRY(launch_gather(net.d_params, net.train.d_bwd_table, (int64_t)net.bwd_table.size(), net.train.d_stream_bwd, s));
     return NERF_OK;
@@ -59,6 +60,8 @@ struct Pass {              // one network evaluated at P = N*S points with every
     std::vector<int> in_ld;
     std::vector<float*> h;       // output of trunk layer i (post ReLU), row stride h_ld[i]
     std::vector<int> h_ld;
+    int precision = NERF_PRECISION_F32;   // the context's arithmetic: F16X2 runs the forward pass on the fp16-pair kernel
+    unsigned* loose = nullptr;            // the context's loose-bound counter (nerf_precision_status)
     float *vcat = nullptr, *hv = nullptr, *raw = nullptr, *d_raw = nullptr;
     float *g_a = nullptr, *g_b = nullptr, *g_hv = nullptr;   // gradient scratch
     std::vector<float*> dz;      // fused backward: d(pre-activation) of trunk layer i, [P, W]
@@ -132,6 +135,17 @@ void carve_pass(Arena& ar, Pass& ps) {
 // also writes what autograd would keep - every trunk layer's post-ReLU output, the feature vector, the view layer's
 // output - into the same buffers the GEMM chain fills, so the backward pass below is unchanged. Same arithmetic class
 // (v_mfma_f32_32x32x2_f32, fp32 accumulate), a different order of the 256 products of a sum.
+// With the context in NERF_PRECISION_F16X2 (the default) that launch is the fp16-pair kernel's STORE variant
+// (mlp_kernel_h2.hip: the contractions at 3 fp16 MFMAs per term, results as close to fp64 as the fp32 chain's), on a stream
+// converted from the plain parameters; NERF_TRAIN_FORWARD=f32 keeps the fp32 kernel. The backward pass is fp32 either way.
+bool pair_forward_allowed() {
+    static const bool on = [] {
+        const char* e = getenv("NERF_TRAIN_FORWARD");
+        return !(e && (e[0] == 'f' || e[0] == 'F') && e[1] == '3');
+    }();
+    return on;
+}
+
 bool gemm_forward_requested() {
     static const bool on = [] {
         const char* e = getenv("NERF_TRAIN_GEMM_FORWARD");
@@ -176,6 +190,29 @@ int forward_pass_fused(Pass& ps, const float* rays, int ray_ld, const float* z, 
         m.st.feat_ld = ps.vcat_ld;
         m.st.hv = ps.hv;
         m.st.hv_ld = a.W / 2;
+    }
+    if (ps.precision == NERF_PRECISION_F16X2 && pair_forward_allowed() && a.use_viewdirs &&
+        (uint64_t)ps.P * (uint64_t)(a.W + a.input_ch + 4) * 4u < ((uint64_t)1 << 32)) {
+        PackedNet& w = const_cast<PackedNet&>(net);      // (a cache of the parameters, like PackedNet::d_stream_h2)
+        TrainState& t = w.train;
+        if (!t.d_stream_h2) {
+            HIP_TRY(hipMalloc((void**)&t.d_stream_h2, (size_t)(net.n_chunks + kStreamTailChunks) * kChunkBytes));
+            HIP_TRY(hipMalloc((void**)&t.d_descale, (kMaxDepth + 3) * sizeof(float)));
+            HIP_TRY(hipMalloc((void**)&t.d_gain, 2 * (kMaxDepth + 2) * sizeof(float)));
+            t.h2_dirty = true;
+        }
+        if (t.h2_dirty) {
+            HIP_TRY(launch_convert_stream_h2(net.d_stream, net.d_chunk_layer, net.n_chunks, net.d_chunk_max, t.d_stream_h2,
+                                             t.d_descale, s));
+            HIP_TRY(launch_layer_gains(net.d_params, gain_refs(net.arch, net.linears), t.d_gain, s));
+            t.h2_dirty = false;
+        }
+        m.stream_h2 = t.d_stream_h2;
+        m.descale = t.d_descale;
+        m.gain = t.d_gain;
+        m.loose = ps.loose;
+        HIP_TRY(launch_mlp_h2(m, kInputRays, s));
+        return NERF_OK;
     }
     HIP_TRY(launch_mlp(m, kInputRays, s));
     return NERF_OK;
@@ -500,6 +537,8 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     pc.P = Pc;
     pc.S = Sc;
     pc.fused_backward = !gemm_backward_requested() && nc.train.d_stream_bwd != nullptr && nc.out_ch == 4;
+    pc.precision = c->precision;
+    pc.loose = c->d_loose;
     carve_pass(ar, pc);
     Pass pf;
     if (Si) {
@@ -508,6 +547,8 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
         pf.P = Pf;
         pf.S = Sf;
         pf.fused_backward = !gemm_backward_requested() && nf.train.d_stream_bwd != nullptr && nf.out_ch == 4;
+        pf.precision = c->precision;
+        pf.loose = c->d_loose;
         carve_pass(ar, pf);
     }
 
