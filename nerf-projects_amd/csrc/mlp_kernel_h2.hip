@@ -144,6 +144,10 @@ __device__ __forceinline__ void keep_pair(const Pending& pd, float y0, float y1)
 template <int T, int Q>
 __device__ __forceinline__ void keep_pairs(const Pending& pd, const f32x2& even, float y0, float y1) {
     const f32x4 v = {even[0], even[1], y0, y1};
+#ifdef NERF_EXP_NOSTORE      // timing experiments (profiles/r02_kernel_ab.md)
+    asm volatile("" ::"v"(v));
+    return;
+#endif
     // (s_nop 1: a store of more than 8 bytes reads its data registers late - two wait states before a vector instruction
     // may overwrite them on gfx950; hipcc's hazard recogniser does not look inside inline asm)
     asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1"
@@ -458,6 +462,9 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             if constexpr (STORE) {
                 pd.keep_base = is_feature ? a.st.feat : a.st.h[l];
                 pd.keep_off = 4u * ((unsigned)pt * (unsigned)(is_feature ? a.st.feat_ld : a.st.h_ld[l]) + 4u * (unsigned)h);
+#ifdef NERF_EXP_STORE_SMALL  // timing experiment: every wave writes the same few KiB (no write traffic to speak of)
+                pd.keep_off = (unsigned)lane * 16u + (unsigned)wave * 4096u;
+#endif
             }
         };
         // all 8 tiles of the pending layer are converted: its true output range

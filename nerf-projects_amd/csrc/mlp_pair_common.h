@@ -194,6 +194,10 @@ __device__ __forceinline__ void run_steps(PipeH& p, Frag4& cur, unsigned fr, uns
 #elif defined(NERF_ABLATE_VMWAIT)
             asm volatile("s_barrier" ::: "memory");
 #else
+#ifdef NERF_EXP_VMCNT      // timing experiment only (profiles/r02_kernel_ab.md): UNSAFE for the ring
+            if constexpr (NB > 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NERF_EXP_VMCNT) : "memory");
+            else
+#endif
             asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
 #endif
             NERF_FENCE();
