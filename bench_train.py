@@ -67,6 +67,8 @@ def main():
                       "ms_per_iter": dt / a.iters * 1e3, "n_rand": a.n_rand, "N_samples": a.samples,
                       "N_importance": a.importance, "mlp_evals_per_iter": evals,
                       "approx_tflops": flops * a.iters / dt / 1e12, "final_loss": float(out["loss"]),
+                      "forward_arithmetic": ("f32" if os.environ.get("NERF_TRAIN_FORWARD", "").lower().startswith("f3") or
+                                             N.get_context().get_precision() != "f16x2" else "f16x2 (fp16-pair kernel)"),
                       "reference_stored_run_it_per_s": "5.6-7.4 (ship 96+192, unknown CUDA GPU; BASELINE.md)"}))
 
 
