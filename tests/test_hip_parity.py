@@ -1008,14 +1008,22 @@ def test_checkpoint_round_trip_with_optimizer_state(N, weights_pair, tmp_path):
     sd = opt.state_dict()
     assert len(sd["state"]) == int(ga["n_params"]) == 48 and float(sd["state"][0]["step"]) == float(ga["step"]) == 2.0
     assert sorted(sd["param_groups"][0].keys()) == [str(k) for k in ga["group_keys"]]
+    def rel_gap(name, i):     # the reference's own fp32 run against its fp64 run, relative to the tensor's largest entry
+        want = ga[f"{name}.{i}"]
+        return np.abs(want - ga[f"{name}.{i}.f64"]).max() / (np.abs(want).max() + 1e-30)
     for i in range(48):
         for name in ("exp_avg", "exp_avg_sq"):
             got, want = sd["state"][i][name].numpy().reshape(-1)[::61], ga[f"{name}.{i}"]
             # 1e-4 of the tensor's largest entry, or - the fine network (i >= 24) inherits the resampling sensitivity of
             # the second iteration's forward pass - 3x the distance between the reference's own fp32 and fp64 runs
-            # of the same two iterations (up to 2 % of the largest entry; tests/golden/make_golden.py)
-            ref_gap = np.abs(want - ga[f"{name}.{i}.f64"]).max()
-            tol = max(1e-4 * (np.abs(want).max() + 1e-30), 3 * ref_gap)
+            # of the same two iterations (up to 2 % of the largest entry; tests/golden/make_golden.py). The fixture keeps
+            # every 61st element, five for a bias: such a sample can sit far below what the same two runs differ by on
+            # the network's other tensors (fine network: median 4.5e-4, this bias 2.5e-5), so the network's MEDIAN
+            # fp32-vs-fp64 distance is a floor for each of its tensors (coarse network: 7e-6, below the 1e-4 anyway)
+            net = range(0, 24) if i < 24 else range(24, 48)
+            floor = float(np.median([rel_gap(name, j) for j in net]))
+            top = np.abs(want).max() + 1e-30
+            tol = max(1e-4 * top, 3 * rel_gap(name, i) * top, floor * top)
             assert np.abs(got - want).max() <= tol, (name, i, np.abs(got - want).max(), tol)
     # torch accepts the layout
     shapes = [tuple(v.shape) for m in (net_c, net_f) for v in m.state_dict().values()]
