@@ -148,6 +148,10 @@ __device__ __forceinline__ void keep_pairs(const Pending& pd, const f32x2& even,
     asm volatile("" ::"v"(v));
     return;
 #endif
+#ifdef NERF_EXP_STORE_BLOCKED
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(pd.keep_off + (8u * T + 2u * Q) * 512u), "v"(v), "s"(pd.keep_base) : "memory");
+    return;
+#endif
     // (s_nop 1: a store of more than 8 bytes reads its data registers late - two wait states before a vector instruction
     // may overwrite them on gfx950; hipcc's hazard recogniser does not look inside inline asm)
     asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1"
@@ -462,6 +466,12 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             if constexpr (STORE) {
                 pd.keep_base = is_feature ? a.st.feat : a.st.h[l];
                 pd.keep_off = 4u * ((unsigned)pt * (unsigned)(is_feature ? a.st.feat_ld : a.st.h_ld[l]) + 4u * (unsigned)h);
+#ifdef NERF_EXP_STORE_BLOCKED  // timing experiment (results are NOT what the backward pass expects): layout blocked by 32 points
+                {
+                    const unsigned ld = (unsigned)(is_feature ? a.st.feat_ld : a.st.h_ld[l]);
+                    pd.keep_off = 4u * (((unsigned)pt >> 5) * 32u * ld + ((unsigned)pt & 31u) * 4u + (unsigned)h * 128u);
+                }
+#endif
 #ifdef NERF_EXP_STORE_SMALL  // timing experiment: every wave writes the same few KiB (no write traffic to speak of)
                 pd.keep_off = (unsigned)lane * 16u + (unsigned)wave * 4096u;
 #endif

@@ -195,7 +195,12 @@ __device__ __forceinline__ void run_steps(PipeH& p, Frag4& cur, unsigned fr, uns
             asm volatile("s_barrier" ::: "memory");
 #else
 #ifdef NERF_EXP_VMCNT      // timing experiment only (profiles/r02_kernel_ab.md): UNSAFE for the ring
-            if constexpr (NB > 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NERF_EXP_VMCNT) : "memory");
+#ifdef NERF_EXP_VMCNT_ALL
+            if constexpr (true)
+#else
+            if constexpr (NB > 0)
+#endif
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NERF_EXP_VMCNT) : "memory");
             else
 #endif
             asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
