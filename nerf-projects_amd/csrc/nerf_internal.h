@@ -270,7 +270,7 @@ struct GradBatch {
 hipError_t launch_grad_batch(GradBatch& b, bool wide, float* part, size_t part_floats, float* dbp, size_t dbp_floats,
                              hipStream_t s);
 hipError_t launch_embed_train(const float* rays, int ray_ld, const float* z, int64_t P, int S, int Lx, int Lv,
-                              float* xcat, int ldx, float* vcat, int ldv, int voff, hipStream_t s);
+                              float* x0, int ld0, float* x1, int ld1, float* vcat, int ldv, int voff, hipStream_t s);
 hipError_t launch_mse(const float* x, const float* t, int64_t n, float* grad, double* part, float* loss, hipStream_t s);
 hipError_t launch_composite_bwd(const float* raw, int C, const float* z, const float* rays_d, int d_ld,
                                 const float* noise, int white_bkgd, int64_t N, int S, const float* g_rgb,

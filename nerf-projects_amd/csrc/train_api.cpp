@@ -154,15 +154,29 @@ bool gemm_forward_requested() {
     return on;
 }
 
+// gamma(x) into layer 0's input and into every concat buffer, gamma(dir) into the view concat buffer: one launch for the
+// usual single skip connection (the kernel writes a second destination), one more per further skip layer
+hipError_t embed_inputs(Pass& ps, const float* rays, int ray_ld, const float* z, int Lx, int Lv, hipStream_t s) {
+    const PackedNet& net = *ps.net;
+    const nerf_arch& a = net.arch;
+    int first = -1;
+    for (int i = 1; i < a.D && first < 0; ++i)
+        if ((net.skip_in_mask >> i) & 1) first = i;
+    hipError_t e = launch_embed_train(rays, ray_ld, z, ps.P, ps.S, Lx, Lv, ps.in[0], ps.in_ld[0],
+                                      first > 0 ? ps.in[first] : nullptr, first > 0 ? ps.in_ld[first] : 0, ps.vcat,
+                                      ps.vcat_ld, a.W, s);
+    for (int i = first + 1; first > 0 && i < a.D && e == hipSuccess; ++i)
+        if ((net.skip_in_mask >> i) & 1)
+            e = launch_embed_train(rays, ray_ld, z, ps.P, ps.S, Lx, 0, ps.in[i], ps.in_ld[i], nullptr, 0, nullptr, 0, 0, s);
+    return e;
+}
+
 int forward_pass_fused(Pass& ps, const float* rays, int ray_ld, const float* z, hipStream_t s) {
     const PackedNet& net = *ps.net;
     const nerf_arch& a = net.arch;
     const int Lx = (a.input_ch - 3) / 6, Lv = a.use_viewdirs ? (a.input_ch_views - 3) / 6 : 0;
     // the encodings are still written out: they are the X of dW = dY^T X for layer 0, the skip layer and the view layer
-    HIP_TRY(launch_embed_train(rays, ray_ld, z, ps.P, ps.S, Lx, Lv, ps.in[0], ps.in_ld[0], ps.vcat, ps.vcat_ld, a.W, s));
-    for (int i = 1; i < a.D; ++i)
-        if ((net.skip_in_mask >> i) & 1)
-            HIP_TRY(launch_embed_train(rays, ray_ld, z, ps.P, ps.S, Lx, 0, ps.in[i], ps.in_ld[i], nullptr, 0, 0, s));
+    HIP_TRY(embed_inputs(ps, rays, ray_ld, z, Lx, Lv, s));
     MlpLaunch m{};
     m.stream = net.d_stream;
     m.bias = net.d_bias;
@@ -226,10 +240,7 @@ int forward_pass(Pass& ps, const float* rays, int ray_ld, const float* z, hipStr
     const float* prm = net.d_params;
     const int Lx = (a.input_ch - 3) / 6, Lv = a.use_viewdirs ? (a.input_ch_views - 3) / 6 : 0;
     // gamma(x) into layer 0's input and into every concat buffer; gamma(dir) into the view concat buffer
-    HIP_TRY(launch_embed_train(rays, ray_ld, z, ps.P, ps.S, Lx, Lv, ps.in[0], ps.in_ld[0], ps.vcat, ps.vcat_ld, a.W, s));
-    for (int i = 1; i < a.D; ++i)
-        if ((net.skip_in_mask >> i) & 1)
-            HIP_TRY(launch_embed_train(rays, ray_ld, z, ps.P, ps.S, Lx, 0, ps.in[i], ps.in_ld[i], nullptr, 0, 0, s));
+    HIP_TRY(embed_inputs(ps, rays, ray_ld, z, Lx, Lv, s));
     for (int i = 0; i < a.D; ++i) {
         const LinearDesc& d = net.linears[i];
         GemmRows g{ps.in[i], ps.in_ld[i], wt + d.w_off, d.out, ps.h[i], ps.h_ld[i], ps.P, d.out, d.in,

@@ -552,46 +552,72 @@ hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, flo
 }
 
 // ---------------------------------------------------------------------------------------------
-// inputs: pts = o + d z, gamma(pts) -> xcat[:, 0:in_ch] (ld ldx), gamma(viewdir) -> vcat[:, voff: voff+in_ch_views]
+// inputs: pts = o + d z, gamma(pts) -> x0[:, 0:in_ch] (ld ld0) and, when given, x1[:, 0:in_ch] (the skip layer's concat
+// buffer), gamma(viewdir) -> vcat[:, voff: voff+in_ch_views]. A workgroup takes 64 points: its threads share the
+// sincosf calls ((point, axis, frequency) items), the rows are put together in LDS and written out with consecutive
+// threads on consecutive floats of a row (a thread per point wrote 63 floats 252 bytes apart from its neighbour's, and
+// every destination was a launch of its own that evaluated the encoding again).
 // ---------------------------------------------------------------------------------------------
-__global__ void embed_train_kernel(const float* __restrict__ rays, int ray_ld, const float* __restrict__ z, int64_t P,
-                                   int S, int Lx, int Lv, float* __restrict__ xcat, int ldx, float* __restrict__ vcat,
-                                   int ldv, int voff) {
-    const int64_t pt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pt >= P) return;
-    const float* r = rays + (pt / S) * ray_ld;
-    const float zz = z[pt];
-    float* xo = xcat + pt * ldx;
-    for (int c = 0; c < 3; ++c) {
-        const float p = __fadd_rn(r[c], __fmul_rn(r[3 + c], zz));   // nerf.ipynb:447
-        xo[c] = p;
-        for (int k = 0; k < Lx; ++k) {
+constexpr int kEmbedPoints = 64;
+__global__ __launch_bounds__(256) void embed_train_kernel(const float* __restrict__ rays, int ray_ld, const float* __restrict__ z,
+                                                          int64_t P, int S, int Lx, int Lv, float* __restrict__ x0, int ld0,
+                                                          float* __restrict__ x1, int ld1, float* __restrict__ vcat, int ldv,
+                                                          int voff) {
+    __shared__ float sx[kEmbedPoints][64];   // 3 + 6 Lx <= 63 columns
+    __shared__ float sv[kEmbedPoints][28];   // 3 + 6 Lv <= 27 columns
+    const int64_t p0 = (int64_t)blockIdx.x * kEmbedPoints;
+    const int n_here = (int)((P - p0) < kEmbedPoints ? (P - p0) : kEmbedPoints);
+    const int fx = Lx + 1, fv = Lv + 1;      // frequency slot 0 is the identity term
+    for (int it = threadIdx.x; it < kEmbedPoints * 3 * fx; it += 256) {
+        const int pl = it / (3 * fx), c = (it / fx) % 3, k = it % fx - 1;
+        if (pl >= n_here) continue;
+        const int64_t pt = p0 + pl;
+        const float* r = rays + (pt / S) * ray_ld;
+        const float p = __fadd_rn(r[c], __fmul_rn(r[3 + c], z[pt]));   // nerf.ipynb:447
+        if (k < 0) {
+            sx[pl][c] = p;
+        } else {
             float sn, cs;
             sincosf(p * (float)(1 << k), &sn, &cs);
-            xo[3 + 6 * k + c] = sn;
-            xo[3 + 6 * k + 3 + c] = cs;
+            sx[pl][3 + 6 * k + c] = sn;
+            sx[pl][3 + 6 * k + 3 + c] = cs;
         }
     }
-    if (vcat) {
-        float* vo = vcat + pt * ldv + voff;
-        for (int c = 0; c < 3; ++c) {
-            const float d = r[ray_ld - 3 + c];
-            vo[c] = d;
-            for (int k = 0; k < Lv; ++k) {
+    if (vcat)
+        for (int it = threadIdx.x; it < kEmbedPoints * 3 * fv; it += 256) {
+            const int pl = it / (3 * fv), c = (it / fv) % 3, k = it % fv - 1;
+            if (pl >= n_here) continue;
+            const float d = rays[((p0 + pl) / S) * ray_ld + ray_ld - 3 + c];
+            if (k < 0) {
+                sv[pl][c] = d;
+            } else {
                 float sn, cs;
                 sincosf(d * (float)(1 << k), &sn, &cs);
-                vo[3 + 6 * k + c] = sn;
-                vo[3 + 6 * k + 3 + c] = cs;
+                sv[pl][3 + 6 * k + c] = sn;
+                sv[pl][3 + 6 * k + 3 + c] = cs;
             }
         }
+    __syncthreads();
+    const int in_ch = 3 + 6 * Lx, in_v = 3 + 6 * Lv;
+    for (int it = threadIdx.x; it < n_here * in_ch; it += 256) {
+        const int pl = it / in_ch, col = it % in_ch;
+        const float v = sx[pl][col];
+        x0[(p0 + pl) * ld0 + col] = v;
+        if (x1) x1[(p0 + pl) * ld1 + col] = v;
     }
+    if (vcat)
+        for (int it = threadIdx.x; it < n_here * in_v; it += 256) {
+            const int pl = it / in_v, col = it % in_v;
+            vcat[(p0 + pl) * ldv + voff + col] = sv[pl][col];
+        }
 }
 
 hipError_t launch_embed_train(const float* rays, int ray_ld, const float* z, int64_t P, int S, int Lx, int Lv,
-                              float* xcat, int ldx, float* vcat, int ldv, int voff, hipStream_t s) {
+                              float* x0, int ld0, float* x1, int ld1, float* vcat, int ldv, int voff, hipStream_t s) {
     if (P <= 0) return hipSuccess;
-    hipLaunchKernelGGL(embed_train_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, rays, ray_ld, z, P, S,
-                       Lx, Lv, xcat, ldx, vcat, ldv, voff);
+    if (Lx < 0 || Lx > 10 || Lv < 0 || Lv > 4 || !x0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(embed_train_kernel, dim3((unsigned)((P + kEmbedPoints - 1) / kEmbedPoints)), dim3(256), 0, s, rays,
+                       ray_ld, z, P, S, Lx, Lv, x0, ld0, x1, ld1, vcat, ldv, voff);
     return hipGetLastError();
 }
 
