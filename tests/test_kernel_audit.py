@@ -32,9 +32,10 @@ def test_no_register_touched_before_its_lds_wait(src, tmp_path):
          os.path.join(build.CSRC, src), "-o", str(out)]
     subprocess.run(cmd, check=True, cwd=tmp_path)
     seen = 0
-    for mode in (0, 1, 2):
-        findings, n_ops, n_waits = audit.audit(str(out), f"kernelILi{mode}")
-        assert n_ops > 1000 and n_waits > 400, (mode, n_ops, n_waits)   # the kernel was found and parsed
-        assert not findings, (mode, findings[:5])
+    # the three input modes of the inference kernel and the training forward kernel (rays, STORE)
+    for inst in ("kernelILi0ELb0E", "kernelILi1ELb0E", "kernelILi2ELb0E", "kernelILi2ELb1E"):
+        findings, n_ops, n_waits = audit.audit(str(out), inst)
+        assert n_ops > 1000 and n_waits > 400, (inst, n_ops, n_waits)   # the kernel was found and parsed
+        assert not findings, (inst, findings[:5])
         seen += 1
-    assert seen == 3
+    assert seen == 4
