@@ -31,7 +31,7 @@ def regs(text):
     return out
 
 
-def audit(path, want="kernelILi2"):
+def audit(path, want="kernelILi2ELb0E"):
     lines = open(path).read().split("\n")
     findings, n_reads, n_waits = [], 0, 0
     name, queue = None, []          # queue: list of (line_no, dest_regs) of LDS ops in flight, oldest first
@@ -75,7 +75,7 @@ def audit(path, want="kernelILi2"):
 
 
 if __name__ == "__main__":
-    f, r, w = audit(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "kernelILi2")
+    f, r, w = audit(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "kernelILi2ELb0E")
     print(f"{sys.argv[1]}: {r} LDS operations, {w} lgkmcnt waits, {len(f)} accesses to registers still in flight")
     for no, text, which in f[:40]:
         print(f"  line {no}: {text}    <- {which}")
