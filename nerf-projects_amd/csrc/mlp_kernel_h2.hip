@@ -787,8 +787,8 @@ __global__ __launch_bounds__(1024) void equalise_rows_kernel(const float* params
         };
         if (r.scale_rows[k]) {
             // binade of the largest row NORM of the layer: with inputs of comparable size a unit's output scales with
-            // the l2 norm of its row (the largest |w| misjudges a row that copies one input next to rows that sum 256)
-            // - rows of zeros and non-finite rows keep factor 1
+            // the l2 norm of its row and bias (the largest |w| misjudges a row that copies one input next to rows that
+            // sum 256) - rows of zeros with a zero bias and non-finite rows keep factor 1
             for (int j = wave; j < n_out; j += n_waves) {
                 const float* w = params + r.w_off[k] + (size_t)j * n_in;
                 double m2 = 0.0;                            // (double: |w| up to FLT_MAX squares without overflow)
@@ -797,6 +797,10 @@ __global__ __launch_bounds__(1024) void equalise_rows_kernel(const float* params
                     m2 += v * v;
                 }
                 for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
+                {   // the bias counts as a weight on a constant input: a row of zeros with a bias is a unit of size |b|
+                    const double bj = (double)params[r.b_off[k] + j];
+                    m2 += bj * bj;
+                }
                 if (lane == 0) {
                     int ej = -1000;
                     if (m2 > 0.0 && m2 < (double)__builtin_inff() * (double)__builtin_inff()) (void)frexp(sqrt(m2), &ej);
