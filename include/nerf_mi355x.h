@@ -94,7 +94,7 @@ void nerf_ctx_destroy(nerf_ctx* ctx);
  *                         range (absolute resolution 2^-24 of the scaled unit) and keeps fewer than 24 bits. So
  *                         that hidden units of very different size do not meet in one group, the kernel evaluates
  *                         a ROW-EQUALISED copy of the network, made at load time and after optimiser steps: unit j
- *                         is scaled by 2^e_j to the largest row norm (weights and bias) of its layer and column j of every layer that
+ *                         is scaled by 2^e_j to the median row norm (weights and bias) of its layer and column j of every layer that
  *                         reads it by 2^-e_j - the same function exactly (ReLU commutes with positive factors, the
  *                         factors are powers of two); nerf_get_weights returns the plain parameters. With it one
  *                         row of a layer 2^20 larger than the others costs nothing, whether its output is used or

@@ -770,13 +770,14 @@ __global__ __launch_bounds__(256) void layer_gain_kernel(const float* params, co
 // Row equalisation (PackedNet::d_params_eq). ReLU commutes with positive factors and feature_linear is linear, so scaling
 // hidden unit j of a layer by s_j = 2^e_j and dividing column j of every layer that reads it by s_j leaves the network's
 // function unchanged - exactly, the factors being powers of two - while every row of a layer gets the same norm
-// binade. The fp16-pair kernel scales a LAYER's weights by one factor and a POINT's activations by one factor: a unit
+// binade (the layer's median). The fp16-pair kernel scales a LAYER's weights by one factor and a POINT's activations by one factor: a unit
 // with weights 2^13 below another's used to lose its low halves, and its small outputs theirs; now neither happens.
 // One workgroup walks the layers in order (a layer's column factors are its producer's row factors); a wavefront takes a
 // row at a time, its lanes along the columns (thread = row made every access a 1 KiB stride: 1.1 ms per network).
 __global__ __launch_bounds__(1024) void equalise_rows_kernel(const float* params, const EqualiseRefs r, float* out) {
     __shared__ int expo[kMaxLinears][256];    // e_j of every linear (0 where rows are not scaled)
     __shared__ int row_exp[256];              // binade of a row's norm, -1000: leave the row alone
+    __shared__ int median_exp;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     for (int idx = 0; idx < r.n; ++idx) {
         const int k = r.order[idx];
@@ -786,7 +787,7 @@ __global__ __launch_bounds__(1024) void equalise_rows_kernel(const float* params
             return (src >= 0 && c >= c0 && c < c1) ? __builtin_ldexpf(v, -expo[src][c - c0]) : v;
         };
         if (r.scale_rows[k]) {
-            // binade of the largest row NORM of the layer: with inputs of comparable size a unit's output scales with
+            // binade of every row's NORM: with inputs of comparable size a unit's output scales with
             // the l2 norm of its row and bias (the largest |w| misjudges a row that copies one input next to rows that
             // sum 256) - rows of zeros with a zero bias and non-finite rows keep factor 1
             for (int j = wave; j < n_out; j += n_waves) {
@@ -808,11 +809,26 @@ __global__ __launch_bounds__(1024) void equalise_rows_kernel(const float* params
                 }
             }
             __syncthreads();
-            int top = -1000;
-            for (int j = 0; j < n_out; ++j) top = max(top, row_exp[j]);
+            // towards the MEDIAN binade, not the largest: the ordinary units keep their scale - a skip layer concatenates
+            // them with gamma(x), whose entries are not scaled, and one huge row must not push 255 others 2^20 above those
+            if (threadIdx.x == 0) median_exp = 0;
+            __syncthreads();
             for (int j = threadIdx.x; j < n_out; j += blockDim.x) {
-                int e = row_exp[j] > -1000 ? top - row_exp[j] : 0;
-                expo[k][j] = e > 30 ? 30 : e;               // a unit 2^30 below the largest is not brought all the way up
+                const int mine = row_exp[j];
+                if (mine <= -1000) continue;
+                int less = 0, leq = 0, valid = 0;
+                for (int q = 0; q < n_out; ++q) {
+                    const int o = row_exp[q];
+                    valid += o > -1000;
+                    less += o > -1000 && o < mine;
+                    leq += o > -1000 && o <= mine;
+                }
+                if (less <= valid / 2 && valid / 2 < leq) median_exp = mine;      // (every such thread writes the same value)
+            }
+            __syncthreads();
+            for (int j = threadIdx.x; j < n_out; j += blockDim.x) {
+                int e = row_exp[j] > -1000 ? median_exp - row_exp[j] : 0;
+                expo[k][j] = e > 30 ? 30 : (e < -30 ? -30 : e);   // a unit 2^30 off the median is not brought all the way
             }
         } else {
             for (int j = threadIdx.x; j < n_out; j += blockDim.x) expo[k][j] = 0;

@@ -90,7 +90,7 @@ struct PackedNet {
     float* d_chunk_max = nullptr;
     float* d_gain = nullptr;     // per layer [max row sum of |W|, max |b|]: bounds a layer's outputs from its inputs
     // What the fp16-pair kernel evaluates is a ROW-EQUALISED copy of the parameters (launch_equalise_rows): the same function,
-    // every hidden unit scaled by a power of two that brings its weight row to the layer's largest row, the factor undone in
+    // every hidden unit scaled by a power of two that brings its weight row (and bias) to the layer's median norm, the factor undone in
     // the columns of the layers that read the unit. The stream, the bias block and the gains of that kernel come from it.
     float* d_params_eq = nullptr;
     float* d_stream_eq = nullptr;   // fp32 stream of the equalised parameters (input of the fp16-pair conversion)

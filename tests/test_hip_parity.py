@@ -237,21 +237,25 @@ def test_fp16_pair_rows_of_unequal_size(N):
     ctx = N.get_context()
     mine = ctx.get_precision()
     try:
-        for shift, dead_end in ((13, True), (20, True), (13, False), (20, False)):
+        # (layer, first hidden column of its consumer): layer 4 feeds the skip layer, which reads cat[gamma(x), h]
+        # (nerf.py:79-80) - units are equalised towards the layer's MEDIAN so that the ordinary ones stay at the scale of
+        # the encoding they are concatenated with
+        for shift, dead_end, layer, col0 in ((13, True, 2, 0), (20, True, 2, 0), (13, False, 2, 0), (20, False, 2, 0),
+                                              (20, False, 4, 63), (20, True, 4, 63)):
             sd = dict(synthetic.synthetic_state_dict(7, **arch))
-            w = np.asarray(sd["pts_linears.2.weight"]).copy()
+            w = np.asarray(sd[f"pts_linears.{layer}.weight"]).copy()
             w[5] *= np.float32(2.0 ** shift)
-            w3 = np.asarray(sd["pts_linears.3.weight"]).copy()
+            w3 = np.asarray(sd[f"pts_linears.{layer + 1}.weight"]).copy()
             if dead_end:
-                w3[:, 5] = 0.0
+                w3[:, col0 + 5] = 0.0
             else:
-                w3[:, 5] *= np.float32(2.0 ** -shift)       # used, at the weight it had
-            if shift == 20 and dead_end:
+                w3[:, col0 + 5] *= np.float32(2.0 ** -shift)       # used, at the weight it had
+            if shift == 20 and dead_end and layer == 2:
                 # rows the equalisation must leave alone: all zeros (no norm to bring up), and one 2^-100 below the rest
                 # (its factor is capped at 2^30: the weights stay normal fp32 numbers)
                 w[9] = 0.0
                 w[11] *= np.float32(2.0 ** -100)
-            sd["pts_linears.2.weight"], sd["pts_linears.3.weight"] = w, w3
+            sd[f"pts_linears.{layer}.weight"], sd[f"pts_linears.{layer + 1}.weight"] = w, w3
             want = _forward_fp64(sd, x, 8, [4], True)
             net = make_net(N, sd, **arch)
             err = {}
@@ -261,8 +265,8 @@ def test_fp16_pair_rows_of_unequal_size(N):
                 e = np.abs(cpu(net(x)).astype(np.float64) - want) / np.abs(want).max(0)
                 assert np.isfinite(e).all()
                 err[prec] = (np.sqrt((e ** 2).mean()), e.max())
-            assert err["f32"][0] <= 2e-6, (shift, dead_end, err)
-            assert err["f16x2"][0] <= 1.5 * err["f32"][0] and err["f16x2"][1] <= 2.0 * err["f32"][1], (shift, dead_end, err)
+            assert err["f32"][0] <= 2e-6, (shift, dead_end, layer, err)
+            assert err["f16x2"][0] <= 1.5 * err["f32"][0] and err["f16x2"][1] <= 2.0 * err["f32"][1], (shift, dead_end, layer, err)
     finally:
         ctx.set_precision(mine)
 
