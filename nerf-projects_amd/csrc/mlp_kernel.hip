@@ -529,6 +529,19 @@ __device__ __forceinline__ void mask_tile(f32x16& kept_then_dst, const f32x16& g
 #pragma unroll
     for (int r = 0; r < 16; ++r) kept_then_dst[r] = kept_then_dst[r] > 0.0f ? g[r] : 0.0f;
 }
+// largest |value| of N tiles over the wavefront, into a float-bits slot (MlpBwdLaunch::maxes); post-ReLU values and
+// magnitudes are non-negative, so the integer maximum of the bit patterns is the float maximum
+template <int N>
+__device__ __forceinline__ void track_max(unsigned* slot, const f32x16 (&t)[8]) {
+    float m = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) m = fmaxf(m, fmaxf(fabsf(t[i][r]), fabsf(t[i][r + 1])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f && m < __builtin_inff()) atomicMax(slot, __float_as_uint(m));
+}
 template <int N>
 __device__ __forceinline__ void zero_tiles(f32x16 (&t)[8]) {
 #pragma unroll
@@ -583,6 +596,7 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
                 chunk_ktile8(pipe, cur, acc, hid[kt], [&]() { store_tile_at(out, hid[kt], kt); });
         }
         activate<8, false>(hid, acc);
+        if (b.maxes) track_max<8>(b.maxes + kBwdMaxFeat, hid);
 
         // d h_{D-1} = W_feature^T d feature + d sigma * w_alpha (alpha row: bias-block tiles 8D+14+t), then its mask
         // The ReLU mask of the layer below is the activation the forward pass kept: 1 KB per point, 128 KB per workgroup
@@ -601,6 +615,7 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
                 });
             load_tile_at(kept, hid[7], 7);
         }
+        if (b.maxes) track_max<8>(b.maxes + kBwdMaxKept + b.D - 1, hid);      // the kept h_{D-1}, before it becomes d z_{D-1}
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const f32x16 wa = *(const f32x16*)(bias_lds + ((8 * b.D + 14 + t) * 2 + h) * 16);
@@ -608,6 +623,7 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
             for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(dsig, wa[r], acc[t][r]);
             mask_tile(hid[t], acc[t]);
         }
+        if (b.maxes) track_max<8>(b.maxes + b.D - 1, hid);
 
         // trunk: d h_{i-1} = W_i[:, hidden]^T d z_i, masked by layer i-1's ReLU
         for (int i = b.D - 1; i >= 1; --i) {
@@ -621,8 +637,10 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
                     if (kt >= 1) load_tile_at(kept, hid[kt - 1], kt - 1);
                 });
             load_tile_at(kept, hid[7], 7);
+            if (b.maxes) track_max<8>(b.maxes + kBwdMaxKept + i - 1, hid);
 #pragma unroll
             for (int t = 0; t < 8; ++t) mask_tile(hid[t], acc[t]);
+            if (b.maxes) track_max<8>(b.maxes + i - 1, hid);
         }
         store_tiles<8>(b.out.h[0], b.out.h_ld[0], hid, pt, h, live);     // d z_0: nothing left to ride behind
     }

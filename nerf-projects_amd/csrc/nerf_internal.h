@@ -160,7 +160,12 @@ struct MlpBwdLaunch {
     int C;
     MlpStore fwd;            // the activations the forward pass kept (ReLU masks): h[i], hv
     MlpStore out;            // h[i] = d(pre-activation of trunk layer i), feat = d feature, hv = d(view pre-activation)
+    // optional [kBwdMaxSlots], zeroed by the caller: the largest |value| of what this pass writes and reads, as float bits
+    // (atomicMax on non-negative floats) - slot i: d(pre-activation) of trunk layer i; kBwdMaxFeat: d feature;
+    // kBwdMaxKept + i: the kept output of trunk layer i. The fp16-pair weight-gradient kernel takes its scales from them.
+    unsigned* maxes;
 };
+constexpr int kBwdMaxFeat = kMaxDepth, kBwdMaxKept = 16, kBwdMaxSlots = 32;
 
 // host-side packer (pack_weights.cpp)
 int pack_weights(const nerf_arch& arch, const float* const* tensors, int n_tensors,
@@ -256,6 +261,8 @@ struct GradJob {
     float* db;                    // nullptr: this job leaves the bias gradient to another one
     float* part;                  // [n_slices][Mo][n_end - n_begin]   (set by launch_grad_batch)
     float* dbp;                   // [n_slices][Mo]
+    const unsigned* a_max;        // fp16-pair kernel only: float bits of the largest |dY| and |X| (MlpBwdLaunch::maxes)
+    const unsigned* b_max;
 };
 constexpr int kMaxGradJobs = 12;
 // points per slice are a multiple of this: whole 32-point tiles for the staged kernel, whole groups of k-steps (two points each,
@@ -267,8 +274,9 @@ struct GradBatch {
     GradJob job[kMaxGradJobs];
 };
 // wide: every job is 256 columns (NT = 4); otherwise at most 64 columns each (NT = 1). scratch: part_floats / dbp_floats available
+// pair: the wide jobs on the fp16 matrix pipe (every job needs a_max / b_max)
 hipError_t launch_grad_batch(GradBatch& b, bool wide, float* part, size_t part_floats, float* dbp, size_t dbp_floats,
-                             hipStream_t s);
+                             hipStream_t s, bool pair = false);
 hipError_t launch_embed_train(const float* rays, int ray_ld, const float* z, int64_t P, int S, int Lx, int Lv,
                               float* x0, int ld0, float* x1, int ld1, float* vcat, int ldv, int voff, hipStream_t s);
 hipError_t launch_mse(const float* x, const float* t, int64_t n, float* grad, double* part, float* loss, hipStream_t s);

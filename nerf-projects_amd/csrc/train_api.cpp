@@ -62,6 +62,7 @@ struct Pass {              // one network evaluated at P = N*S points with every
     std::vector<int> h_ld;
     int precision = NERF_PRECISION_F32;   // the context's arithmetic: F16X2 runs the forward pass on the fp16-pair kernel
     unsigned* loose = nullptr;            // the context's loose-bound counter (nerf_precision_status)
+    unsigned* maxes = nullptr;            // [kBwdMaxSlots] largest |values| of the backward pass (MlpBwdLaunch::maxes)
     float *vcat = nullptr, *hv = nullptr, *raw = nullptr, *d_raw = nullptr;
     float *g_a = nullptr, *g_b = nullptr, *g_hv = nullptr;   // gradient scratch
     std::vector<float*> dz;      // fused backward: d(pre-activation) of trunk layer i, [P, W]
@@ -125,8 +126,10 @@ void carve_pass(Arena& ar, Pass& ps) {
     ps.g_b = ar.take((size_t)P * a.W);
     ps.g_hv = ar.take((size_t)P * (a.W / 2));
     ps.dz.assign(a.D, nullptr);
-    if (ps.fused_backward)
+    if (ps.fused_backward) {
         for (int i = 0; i < a.D; ++i) ps.dz[i] = ar.take((size_t)P * a.W);     // d(pre-activation) of every trunk layer
+        ps.maxes = (unsigned*)ar.take(kBwdMaxSlots);
+    }
 }
 
 // The training forward pass. NERF_TRAIN_GEMM_FORWARD=1 in the environment (or a network the fused kernel's store
@@ -141,6 +144,16 @@ void carve_pass(Arena& ar, Pass& ps) {
 bool pair_forward_allowed() {
     static const bool on = [] {
         const char* e = getenv("NERF_TRAIN_FORWARD");
+        return !(e && (e[0] == 'f' || e[0] == 'F') && e[1] == '3');
+    }();
+    return on;
+}
+
+// The wide weight-gradient jobs follow the context's precision as well: NERF_PRECISION_F16X2 runs them on the fp16 pipe
+// (train_dw_kernel.hip, grad_batch_pair_kernel); NERF_TRAIN_DW=f32 keeps the fp32 kernel.
+bool pair_dw_allowed() {
+    static const bool on = [] {
+        const char* e = getenv("NERF_TRAIN_DW");
         return !(e && (e[0] == 'f' || e[0] == 'F') && e[1] == '3');
     }();
     return on;
@@ -347,6 +360,11 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     b.out.hv_ld = views.out;
     b.out.feat = d_feat;
     b.out.feat_ld = a.W;
+    const bool pair_dw = ps.precision == NERF_PRECISION_F16X2 && pair_dw_allowed() && ps.maxes != nullptr;
+    if (pair_dw) {
+        HIP_TRY(hipMemsetAsync(ps.maxes, 0, kBwdMaxSlots * sizeof(unsigned), s));
+        b.maxes = ps.maxes;
+    }
     HIP_TRY(launch_mlp_bwd(b, s));
     const float* hl = ps.h[a.D - 1];
     const int hl_ld = ps.h_ld[a.D - 1];
@@ -366,26 +384,31 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     // gamma(x) / gamma(d) columns. With J jobs in a launch a layer is cut into 256 / J slices instead of 256: J times
     // fewer partial sums to write and to add up (a layer's 256 partials were 67 MB, and the pass over them 12 % of the step).
     float* grad = net.train.d_grad;
-    GradBatch wide{}, narrow{};
+    // (pairs: the jobs whose operands the backward kernel has measured - d z_i / d feature against the kept h_{i-1} - go to
+    // the fp16-pair kernel when the context's arithmetic is F16X2; the view layer's job reads the feature vector, which that
+    // kernel does not touch, and stays on the fp32 kernel)
+    GradBatch wide{}, narrow{}, pairs{};
     auto job = [&](GradBatch& b, const LinearDesc& d, const float* dY, int ldy, const float* X, int ldx, int n0, int n1,
-                   bool with_db) {
+                   bool with_db, const unsigned* a_max = nullptr, const unsigned* b_max = nullptr) {
         b.job[b.n++] = GradJob{dY, ldy, X, ldx, d.out, n0, n1, grad + d.w_off, d.in, with_db ? grad + d.b_off : nullptr,
-                               nullptr, nullptr};
+                               nullptr, nullptr, a_max, b_max};
     };
-    job(wide, feat, d_feat, a.W, hl, hl_ld, 0, a.W, true);
+    GradBatch& hidden = pair_dw ? pairs : wide;
+    auto mx = [&](int slot) -> const unsigned* { return pair_dw ? ps.maxes + slot : nullptr; };
+    job(hidden, feat, d_feat, a.W, hl, hl_ld, 0, a.W, true, mx(kBwdMaxFeat), mx(kBwdMaxKept + a.D - 1));
     job(wide, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, 0, a.W, true);          // cat[feature, gamma(d)] (nerf.py:93)
     if (views.in > a.W) job(narrow, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, a.W, views.in, false);
     for (int i = a.D - 1; i >= 0; --i) {
         const LinearDesc& d = net.linears[i];
         if (d.in >= a.W) {
             const int lead = d.in - a.W;                                               // cat[gamma(x), h] (nerf.py:79-80)
-            job(wide, d, ps.dz[i], a.W, ps.in[i], ps.in_ld[i], lead, d.in, true);
+            job(hidden, d, ps.dz[i], a.W, ps.in[i], ps.in_ld[i], lead, d.in, true, mx(i), mx(kBwdMaxKept + i - 1));
             if (lead > 0) job(narrow, d, ps.dz[i], a.W, ps.in[i], ps.in_ld[i], 0, lead, false);
         } else {
             job(narrow, d, ps.dz[i], a.W, ps.in[i], ps.in_ld[i], 0, d.in, true);       // layer 0: gamma(x) only
         }
     }
-    for (GradBatch* b : {&wide, &narrow}) {
+    for (GradBatch* b : {&pairs, &wide, &narrow}) {
         if (b->n == 0) continue;
         int n_slices = 256 / b->n;
         const int64_t cap = (ps.P + 255) / 256;
@@ -397,7 +420,7 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
         b->pts_per_slice = pps;
         b->P = ps.P;
         b->accumulate = sc.accumulate;
-        HIP_TRY(launch_grad_batch(*b, b == &wide, sc.part, sc.part_floats, sc.dbp, sc.dbp_floats, s));
+        HIP_TRY(launch_grad_batch(*b, b != &narrow, sc.part, sc.part_floats, sc.dbp, sc.dbp_floats, s, b == &pairs));
     }
     return NERF_OK;
 }

@@ -155,6 +155,163 @@ void grad_batch_kernel(const GradBatch b) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The wide jobs on the fp16 matrix pipe ("fp16-pair" arithmetic, as mlp_kernel_h2.hip: every operand as hi = rn16(v),
+// lo = rn16(v - hi), a product as lo*hi + hi*lo + hi*hi in three v_mfma_f32_32x32x16_f16, fp32 accumulate). The
+// contraction runs over POINTS, so each operand takes ONE power-of-two scale per tensor (largest |value| -> [2^13, 2^14);
+// the maxima come from the backward-data kernel, which writes dY and reads X anyway), undone once on the accumulators.
+// v_mfma_f32_32x32x16_f16 wants eight points per lane and feature where the fp32 instruction wanted one: lane (i, kh)
+// loads its 16 bytes (four features of one point) for the eight points 8 kh .. 8 kh + 7 of a 16-point step, and the
+// split is register-local - feature t of those eight points is fragment t. 48 MFMAs (1 536 matrix-pipe cycles) per step
+// and wave against ~200 vector instructions; two register sets, the next step's sixteen loads issued before this step's
+// arithmetic.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void pair_split(float a0, float a1, unsigned& hi, unsigned& lo) {
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "s_nop 0\n\t"
+        "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(hi), "=&v"(lo)
+        : "v"(a0), "v"(a1));
+}
+__device__ __forceinline__ f32x16 mfma16h(const u32x4& a, const u32x4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ int pair_scale_exponent(const unsigned* bits) {
+    const float m = __uint_as_float(*bits);
+    if (!(m > 0.0f) || !(m < __builtin_inff())) return 0;
+    const int e = 14 - __builtin_amdgcn_frexp_expf(m);
+    return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+
+struct PairSet {
+    f32x4u a[8], b[8];
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void grad_batch_pair_kernel(const GradBatch b) {
+    const GradJob& g = b.job[blockIdx.y];
+    const int n_begin = g.n_begin, n_end = g.n_end, width = n_end - n_begin;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kh = lane >> 5, i = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m_base = 128 * wm;
+    if (m_base >= g.Mo) return;                 // (no barrier anywhere below)
+    const int slice = blockIdx.x;
+    const int c_base = n_begin + 128 * wn;       // this wave's first column
+    if (c_base >= n_end) return;
+    const int col = c_base + 4 * i;
+    const int64_t p_begin = (int64_t)slice * b.pts_per_slice;
+    int64_t p_end = p_begin + b.pts_per_slice;
+    if (p_end > b.P) p_end = b.P;
+    const int64_t n_pts = p_end > p_begin ? p_end - p_begin : 0;
+    const int n_steps = (int)(n_pts / 16);
+
+    const int ea = pair_scale_exponent(g.a_max), eb = pair_scale_exponent(g.b_max);
+    const float sa = __builtin_ldexpf(1.0f, ea), sb = __builtin_ldexpf(1.0f, eb);
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
+    float asum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    const float* pa = g.A + (p_begin + 8 * kh) * g.lda + m_base + 4 * i;
+    const float* pb = g.B + (p_begin + 8 * kh) * g.ldb + col;
+    const int64_t step_a = 16 * (int64_t)g.lda, step_b = 16 * (int64_t)g.ldb;
+
+    auto load = [&](PairSet& r) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            r.a[j] = *(const f32x4u*)(pa + j * (int64_t)g.lda);
+            r.b[j] = *(const f32x4u*)(pb + j * (int64_t)g.ldb);
+        }
+        pa += step_a;
+        pb += step_b;
+    };
+    auto step = [&](const PairSet& r) {
+        u32x4 ahi[4], alo[4], bhi[4], blo[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float a0 = r.a[2 * q][t], a1 = r.a[2 * q + 1][t];
+                asum[t] += a0 + a1;
+                unsigned hi, lo;
+                pair_split(a0 * sa, a1 * sa, hi, lo);
+                ahi[t][q] = hi;
+                alo[t][q] = lo;
+                pair_split(r.b[2 * q][t] * sb, r.b[2 * q + 1][t] * sb, hi, lo);
+                bhi[t][q] = hi;
+                blo[t][q] = lo;
+            }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                acc[tm][tn] = mfma16h(alo[tm], bhi[tn], acc[tm][tn]);
+                acc[tm][tn] = mfma16h(ahi[tm], blo[tn], acc[tm][tn]);
+                acc[tm][tn] = mfma16h(ahi[tm], bhi[tn], acc[tm][tn]);
+            }
+    };
+
+    PairSet r0, r1;
+    int s = 0;
+    if (n_steps > 0) load(r0);
+    for (; s + 2 <= n_steps; s += 2) {
+        load(r1);
+        step(r0);
+        if (s + 2 < n_steps) load(r0);
+        step(r1);
+    }
+    if (s < n_steps) {
+        step(r0);
+        ++s;
+    }
+    // the tail: fewer than sixteen points, loads predicated per lane and point
+    const int64_t p_tail = p_begin + 16 * (int64_t)s;
+    if (p_tail < p_end) {
+        PairSet r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t p = p_tail + 8 * kh + j;
+            const f32x4u z = {0.0f, 0.0f, 0.0f, 0.0f};
+            r.a[j] = z;
+            r.b[j] = z;
+            if (p < p_end) {
+                r.a[j] = *(const f32x4u*)(g.A + p * g.lda + m_base + 4 * i);
+                r.b[j] = *(const f32x4u*)(g.B + p * g.ldb + col);
+            }
+        }
+        step(r);
+    }
+
+    // acc[tm][tn][r] at lane (j = i, h = kh): row m_base + 4 (r&3 + 8 (r>>2) + 4 h) + tm, column c_base + 4 j + tn
+    const float descale = __builtin_ldexpf(1.0f, -(ea + eb));
+    float* part = g.part + (int64_t)slice * g.Mo * width - n_begin;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m_base + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + tm;
+            float* dst = part + (int64_t)m * width + c_base + 4 * i;
+            const f32x4u v = {acc[tm][0][r] * descale, acc[tm][1][r] * descale, acc[tm][2][r] * descale, acc[tm][3][r] * descale};
+            *(f32x4u*)dst = v;
+        }
+    if (g.db && wn == 0) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            const float t = asum[tm] + __shfl_xor(asum[tm], 32);
+            if (kh == 0) g.dbp[(int64_t)slice * g.Mo + m_base + 4 * i + tm] = t;
+        }
+    }
+}
+
 // part[s][m][c] summed over the slices in order (deterministic) into dW[m][n_begin + c]; thread = four consecutive elements
 // of one job (eight 16-byte loads in flight), the bias gradients behind them
 __global__ __launch_bounds__(256) void grad_batch_reduce_kernel(const GradBatch b) {
@@ -200,7 +357,7 @@ __global__ __launch_bounds__(256) void grad_batch_reduce_kernel(const GradBatch 
 }
 
 hipError_t launch_grad_batch(GradBatch& b, bool wide, float* part, size_t part_floats, float* dbp, size_t dbp_floats,
-                             hipStream_t s) {
+                             hipStream_t s, bool pair) {
     if (b.n <= 0) return hipSuccess;
     if (b.n > kMaxGradJobs || b.n_slices <= 0) return hipErrorInvalidValue;
     size_t used = 0, used_db = 0;
@@ -209,6 +366,7 @@ hipError_t launch_grad_batch(GradBatch& b, bool wide, float* part, size_t part_f
         GradJob& g = b.job[j];
         const int width = g.n_end - g.n_begin;
         if (g.Mo % 128 != 0 || g.Mo > 256 || width <= 0 || (wide ? width != 256 : width > 64)) return hipErrorInvalidValue;
+        if (pair && (!wide || !g.a_max || !g.b_max || (g.lda & 3) || (g.ldb & 3))) return hipErrorInvalidValue;
         g.part = part + used;
         g.dbp = dbp + used_db;
         used += (size_t)b.n_slices * g.Mo * width;
@@ -218,7 +376,8 @@ hipError_t launch_grad_batch(GradBatch& b, bool wide, float* part, size_t part_f
     }
     if (used > part_floats || used_db > dbp_floats) return hipErrorInvalidValue;
     const dim3 grid((unsigned)b.n_slices, (unsigned)b.n);
-    if (wide) hipLaunchKernelGGL(grad_batch_kernel<4>, grid, dim3(256), 0, s, b);
+    if (pair) hipLaunchKernelGGL(grad_batch_pair_kernel, grid, dim3(256), 0, s, b);
+    else if (wide) hipLaunchKernelGGL(grad_batch_kernel<4>, grid, dim3(256), 0, s, b);
     else hipLaunchKernelGGL(grad_batch_kernel<1>, grid, dim3(256), 0, s, b);
     hipLaunchKernelGGL(grad_batch_reduce_kernel, dim3((unsigned)((max_threads + 255) / 256), (unsigned)b.n), dim3(256), 0, s, b);
     return hipGetLastError();
