@@ -530,17 +530,33 @@ __device__ __forceinline__ void mask_tile(f32x16& kept_then_dst, const f32x16& g
     for (int r = 0; r < 16; ++r) kept_then_dst[r] = kept_then_dst[r] > 0.0f ? g[r] : 0.0f;
 }
 // largest |value| of N tiles over the wavefront, into a float-bits slot (MlpBwdLaunch::maxes); post-ReLU values and
-// magnitudes are non-negative, so the integer maximum of the bit patterns is the float maximum
+// magnitudes are non-negative, so the integer maximum of the bit patterns is the float maximum. The wave's maximum by six
+// DPP folds (no LDS round trips), and the atomic only when the slot - read through the scalar cache, possibly stale, which
+// only costs an atomic more - does not hold as much already: a thousand waves otherwise queue on one address per layer
+// (+12 % on the kernel); after the first tiles almost none is issued.
 template <int N>
 __device__ __forceinline__ void track_max(unsigned* slot, const f32x16 (&t)[8]) {
+    const unsigned known = *(const unsigned*)slot;
     float m = 0.0f;
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) m = fmaxf(m, fmaxf(fabsf(t[i][r]), fabsf(t[i][r + 1])));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.0f && m < __builtin_inff()) atomicMax(slot, __float_as_uint(m));
+    int v = __float_as_int(m);
+#define NERF_FOLD(ctrl, rows)                                                       \
+    {                                                                               \
+        const int o = __builtin_amdgcn_update_dpp(0, v, ctrl, rows, 0xf, false);    \
+        v = o > v ? o : v;                                                          \
+    }
+    NERF_FOLD(0xB1, 0xf)      // quad_perm [1,0,3,2]
+    NERF_FOLD(0x4E, 0xf)      // quad_perm [2,3,0,1]
+    NERF_FOLD(0x141, 0xf)     // row_half_mirror
+    NERF_FOLD(0x140, 0xf)     // row_mirror
+    NERF_FOLD(0x142, 0xa)     // row_bcast:15 into rows 1 and 3
+    NERF_FOLD(0x143, 0xc)     // row_bcast:31 into rows 2 and 3
+#undef NERF_FOLD
+    const unsigned top = (unsigned)__builtin_amdgcn_readlane(v, 63);
+    if ((threadIdx.x & 63) == 0 && top > known && top < 0x7f800000u) atomicMax(slot, top);
 }
 template <int N>
 __device__ __forceinline__ void zero_tiles(f32x16 (&t)[8]) {
@@ -585,6 +601,7 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
             for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(d2, w2[r], fmaf(d1, w1[r], d0 * w0[r]));
         }
         mask_tiles<4>(hid, acc, b.fwd.hv, b.fwd.hv_ld, pt, h);
+        if (b.maxes) track_max<4>(b.maxes + kBwdMaxViews, hid);
 
         // every gradient tile goes to memory behind the barrier of the chunk that contracts over it (see run_steps)
         // d feature = W_views[:, :W]^T d(view pre-activation)

@@ -161,11 +161,14 @@ struct MlpBwdLaunch {
     MlpStore fwd;            // the activations the forward pass kept (ReLU masks): h[i], hv
     MlpStore out;            // h[i] = d(pre-activation of trunk layer i), feat = d feature, hv = d(view pre-activation)
     // optional [kBwdMaxSlots], zeroed by the caller: the largest |value| of what this pass writes and reads, as float bits
-    // (atomicMax on non-negative floats) - slot i: d(pre-activation) of trunk layer i; kBwdMaxFeat: d feature;
+    // (atomicMax on non-negative floats) - slot i: d(pre-activation) of trunk layer i; kBwdMaxFeat: d feature; kBwdMaxViews;
     // kBwdMaxKept + i: the kept output of trunk layer i. The fp16-pair weight-gradient kernel takes its scales from them.
     unsigned* maxes;
 };
-constexpr int kBwdMaxFeat = kMaxDepth, kBwdMaxKept = 16, kBwdMaxSlots = 32;
+constexpr int kBwdMaxFeat = kMaxDepth, kBwdMaxViews = kMaxDepth + 1, kBwdMaxKept = 16, kBwdMaxFeatValue = 30, kBwdMaxSlots = 32;
+// kBwdMaxViews: d(view pre-activation); kBwdMaxFeatValue: a BOUND of |feature| (the backward kernel does not read the feature
+// vector): largest row sum of |W_feature| x largest kept h_{D-1} + largest |b| (launch_feature_bound, from the gain table)
+hipError_t launch_feature_bound(const float* gain_feature, unsigned* maxes, int D, hipStream_t s);
 
 // host-side packer (pack_weights.cpp)
 int pack_weights(const nerf_arch& arch, const float* const* tensors, int n_tensors,

@@ -366,6 +366,10 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
         b.maxes = ps.maxes;
     }
     HIP_TRY(launch_mlp_bwd(b, s));
+    // the view layer's job can join the fp16-pair batch when |feature| is bounded: gain table of the plain parameters (made
+    // for the fp16-pair forward pass of this iteration) x the largest kept h_{D-1}
+    const float* gain_feat = (pair_dw && net.train.d_gain && !net.train.h2_dirty) ? net.train.d_gain + 2 * a.D : nullptr;
+    if (gain_feat) HIP_TRY(launch_feature_bound(gain_feat, ps.maxes, a.D, s));
     const float* hl = ps.h[a.D - 1];
     const int hl_ld = ps.h_ld[a.D - 1];
     int rc;
@@ -384,9 +388,8 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     // gamma(x) / gamma(d) columns. With J jobs in a launch a layer is cut into 256 / J slices instead of 256: J times
     // fewer partial sums to write and to add up (a layer's 256 partials were 67 MB, and the pass over them 12 % of the step).
     float* grad = net.train.d_grad;
-    // (pairs: the jobs whose operands the backward kernel has measured - d z_i / d feature against the kept h_{i-1} - go to
-    // the fp16-pair kernel when the context's arithmetic is F16X2; the view layer's job reads the feature vector, which that
-    // kernel does not touch, and stays on the fp32 kernel)
+    // (pairs: the jobs whose operands the backward kernel has measured - d z_i / d feature against the kept h_{i-1}, the
+    // view layer's against a bound of the feature vector - go to the fp16-pair kernel when the context's arithmetic is F16X2)
     GradBatch wide{}, narrow{}, pairs{};
     auto job = [&](GradBatch& b, const LinearDesc& d, const float* dY, int ldy, const float* X, int ldx, int n0, int n1,
                    bool with_db, const unsigned* a_max = nullptr, const unsigned* b_max = nullptr) {
@@ -396,7 +399,8 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     GradBatch& hidden = pair_dw ? pairs : wide;
     auto mx = [&](int slot) -> const unsigned* { return pair_dw ? ps.maxes + slot : nullptr; };
     job(hidden, feat, d_feat, a.W, hl, hl_ld, 0, a.W, true, mx(kBwdMaxFeat), mx(kBwdMaxKept + a.D - 1));
-    job(wide, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, 0, a.W, true);          // cat[feature, gamma(d)] (nerf.py:93)
+    job(gain_feat ? pairs : wide, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, 0, a.W, true, mx(kBwdMaxViews),
+        mx(kBwdMaxFeatValue));                                                        // cat[feature, gamma(d)] (nerf.py:93)
     if (views.in > a.W) job(narrow, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, a.W, views.in, false);
     for (int i = a.D - 1; i >= 0; --i) {
         const LinearDesc& d = net.linears[i];

@@ -312,6 +312,18 @@ void grad_batch_pair_kernel(const GradBatch b) {
     }
 }
 
+__global__ void feature_bound_kernel(const float* gain_feature, unsigned* maxes, int D) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float h = __uint_as_float(maxes[kBwdMaxKept + D - 1]);
+        const float bound = fmaf(gain_feature[0], h, gain_feature[1]);
+        maxes[kBwdMaxFeatValue] = (bound > 0.0f && bound < __builtin_inff()) ? __float_as_uint(bound) : 0u;
+    }
+}
+hipError_t launch_feature_bound(const float* gain_feature, unsigned* maxes, int D, hipStream_t s) {
+    hipLaunchKernelGGL(feature_bound_kernel, dim3(1), dim3(64), 0, s, gain_feature, maxes, D);
+    return hipGetLastError();
+}
+
 // part[s][m][c] summed over the slices in order (deterministic) into dW[m][n_begin + c]; thread = four consecutive elements
 // of one job (eight 16-byte loads in flight), the bias gradients behind them
 __global__ __launch_bounds__(256) void grad_batch_reduce_kernel(const GradBatch b) {
