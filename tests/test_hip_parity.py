@@ -958,6 +958,46 @@ def test_training_runs_agree_between_forward_arithmetics(N, weights_pair):
     assert a[-5:].mean() < 0.75 * a[:5].mean() and b[-5:].mean() < 0.75 * b[:5].mean(), (a, b)
 
 
+def test_train_gradients_with_a_wide_range_of_ray_errors(N, weights_pair):
+    """The fp16-pair weight-gradient kernel scales dY by ONE power of two per layer (the contraction runs over points): a
+    batch in which eight rays are wrong by O(1) and the other 1 016 by 1e-6 spreads dY over six decades. Gradients of the
+    fp16-pair path (forward and weight gradients on the fp16 pipe) against the all-fp32 path on the same batch: every
+    tensor of the coarse network within 1e-5 of its largest entry (twice the bar each path meets against the reference's
+    autograd). The fine network sees the same spread but its samples are drawn from the coarse pass's weights: with eight
+    rays carrying the gradient, one of their 192 samples landing in a neighbouring bin moves a tensor by 1/8 x 1/192 = 6.5e-4
+    of its largest entry, so its bar is 1e-3 (measured 7.8e-5) - it guards against a gross loss of range, which would be
+    orders of magnitude."""
+    g, net_c, net_f, kw, batch_rays, _ = _train_setup(N, weights_pair)
+    kw = dict(kw, perturb=0.0, raw_noise_std=0.0)
+    ctx = N.get_context()
+    mine = ctx.get_precision()
+    try:
+        ctx.set_precision("f32")
+        opt = N.Adam([net_c, net_f], lr=5e-4)
+        n = batch_rays[0].shape[0]
+        base = N.train_on_batch(800, 800, None, batch_rays, torch.zeros(n, 3, device="cuda"), opt, apply_update=False, **kw)
+        torch.manual_seed(3)
+        target = base["rgb"].detach().clone() + 1e-6 * torch.randn(n, 3, device="cuda")
+        target[::n // 8][:8] += 0.7
+        grads = {}
+        for prec in ("f32", "f16x2"):
+            ctx.set_precision(prec)
+            N.train_on_batch(800, 800, None, batch_rays, target, opt, apply_update=False, **kw)
+            grads[prec] = {(tag, k): v.numpy().copy() for tag, net in (("c", net_c), ("f", net_f))
+                           for k, v in net.grad_dict().items()}
+    finally:
+        ctx.set_precision(mine)
+    worst = {"c": 0.0, "f": 0.0}
+    for key, a in grads["f32"].items():
+        b = grads["f16x2"][key]
+        top = np.abs(a).max()
+        assert np.isfinite(b).all(), key
+        if top > 0:
+            worst[key[0]] = max(worst[key[0]], np.abs(a - b).max() / top)
+            assert np.abs(a - b).max() <= (1e-5 if key[0] == "c" else 1e-3) * top, (key, np.abs(a - b).max(), top)
+    print("largest difference between the arithmetics, of a tensor's largest gradient: coarse %.2e, fine %.2e" % (worst["c"], worst["f"]))
+
+
 def test_train_gradients_of_ragged_batches_add_up(N, weights_pair):
     """The weight-gradient kernels cut the points of a pass into slices of two-point steps (csrc/train_dw_kernel.hip): odd
     point counts, slices that end mid-step and passes shorter than the prefetch depth take their tail paths, which the
