@@ -188,12 +188,15 @@ def train_leg(N, synthetic, iters=30, warmup=5, n_rand=1024, Sc=64, Si=128):
     tf = evals * FLOP_PER_EVAL * 3 * iters / dt / 1e12          # forward + dX + dW
     pair_forward = (N.get_context().get_precision() == "f16x2" and
                     not os.environ.get("NERF_TRAIN_FORWARD", "").lower().startswith("f3"))
+    pair_dw = (N.get_context().get_precision() == "f16x2" and
+               not os.environ.get("NERF_TRAIN_DW", "").lower().startswith("f3"))
     return {"metric": "train_iterations_per_sec", "value": iters / dt, "unit": "it/s", "iters": iters,
             "ms_per_iter": dt / iters * 1e3, "n_rand": n_rand, "N_samples": Sc, "N_importance": Si,
             "tflops_effective": tf, "frac_of_fp32_mfma_peak": tf / PEAK_FP32_MFMA_TFLOPS,
             "arithmetic": ("forward: fp16-pair kernel (3 x v_mfma_f32_32x32x16_f16 per term, fp32 accumulate, fp32-level error); "
                            if pair_forward else "forward: f32; ") +
-                          "backward-data, weight gradients, Adam: f32 (v_mfma_f32_32x32x2_f32), fp32 master weights",
+                          ("hidden-width weight gradients: fp16-pair; " if pair_dw else "") +
+                          "backward-data, other weight gradients, Adam: f32 (v_mfma_f32_32x32x2_f32), fp32 master weights",
             "final_loss": float(out["loss"]),
             "reference_stored_run": "5.6-7.4 it/s (ship 96+192, unknown CUDA GPU; BASELINE.md section 1)"}
 

@@ -300,9 +300,9 @@ int nerf_image_metrics(nerf_ctx* ctx, const float* img1 /*[dev] [H,W,3]*/, const
  * on the master fp32 copy of the weights that nerf_load_weights keeps on the device. Afterwards the
  * inference entry points see the updated weights. The caller owns the RNG (t_rand, u_rand, noise*, as in
  * nerf_render_args), the ray batching and the learning-rate schedule (nerf.ipynb:1278-1282).
- * Arithmetic: the forward pass follows nerf_set_precision (NERF_PRECISION_F16X2: the fp16-pair kernel, whose error is
- * the fp32 kernel's; NERF_TRAIN_FORWARD=f32 in the environment keeps fp32); backward-data, weight gradients, Adam and
- * the master weights are fp32 always.
+ * Arithmetic: the forward pass and the hidden-width weight gradients follow nerf_set_precision (NERF_PRECISION_F16X2:
+ * fp16-pair arithmetic, whose error is the fp32 kernels'; NERF_TRAIN_FORWARD=f32 / NERF_TRAIN_DW=f32 in the environment
+ * keep fp32); backward-data, the other weight gradients, Adam and the master weights are fp32 always.
  */
 typedef struct nerf_train_args {
     const float* rays;          /* [dev] [N, 8|11] as render() packs them                       */
