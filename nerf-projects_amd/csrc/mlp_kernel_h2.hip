@@ -733,30 +733,30 @@ __global__ __launch_bounds__(256) void convert_stream_h2_kernel(const float* str
 }
 
 // gain[2l] = max over output rows of sum_k |W[row][k]|, gain[2l+1] = max |bias|, for the layers whose outputs
-// are re-quantised (see Pending). Grid (layer, row group of 64): four threads share a row; the per-layer maxima are
-// combined with integer atomicMax on the bit patterns (non-negative floats order like their bits; a maximum does not
-// depend on the order of its operands, so the result is deterministic). `gain` is zeroed by the launcher.
+// are re-quantised (see Pending). Grid (layer, row group of 16): a wavefront takes a row at a time, its lanes along the
+// row (four threads per row read 16 bytes of each of 16 rows per step and made 80 dependent steps: 27 us; the training
+// step runs this after every optimiser step); the per-layer maxima are combined with integer atomicMax on the bit patterns
+// (non-negative floats order like their bits; a maximum does not depend on the order of its operands, so the result is
+// deterministic). `gain` is zeroed by the launcher.
+constexpr int kGainRowsPerBlock = 16;
 __global__ __launch_bounds__(256) void layer_gain_kernel(const float* params, const GainRefs refs, float* gain) {
     __shared__ float red[2][4];
-    const int l = blockIdx.x;
-    const int row = blockIdx.y * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3;
+    const int l = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_in = refs.in[l];
-    float s = 0.0f, bm = 0.0f;
-    if (row < refs.out[l]) {
+    float g = 0.0f, bm = 0.0f;
+    for (int r = wave; r < kGainRowsPerBlock; r += 4) {
+        const int row = blockIdx.y * kGainRowsPerBlock + r;
+        if (row >= refs.out[l]) break;
         const float* w = params + refs.w_off[l] + (size_t)row * n_in;
-        for (int k = part; k < n_in; k += 4) s += fabsf(w[k]);
-        if (part == 0) bm = fabsf(params[refs.b_off[l] + row]);
+        float s = 0.0f;
+        for (int k = lane; k < n_in; k += 64) s += fabsf(w[k]);
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        g = fmaxf(g, s);
+        bm = fmaxf(bm, fabsf(params[refs.b_off[l] + row]));
     }
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    float g = s;
-    for (int o = 32; o > 0; o >>= 1) {
-        g = fmaxf(g, __shfl_xor(g, o));
-        bm = fmaxf(bm, __shfl_xor(bm, o));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        red[0][threadIdx.x >> 6] = g;
-        red[1][threadIdx.x >> 6] = bm;
+    if (lane == 0) {
+        red[0][wave] = g;
+        red[1][wave] = bm;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -859,7 +859,8 @@ hipError_t launch_layer_gains(const float* params, const GainRefs& refs, float* 
     if (e != hipSuccess) return e;
     int max_out = 1;
     for (int l = 0; l < refs.n; ++l) max_out = refs.out[l] > max_out ? refs.out[l] : max_out;
-    hipLaunchKernelGGL(layer_gain_kernel, dim3(refs.n, (max_out + 63) / 64), dim3(256), 0, s, params, refs, gain);
+    hipLaunchKernelGGL(layer_gain_kernel, dim3(refs.n, (max_out + kGainRowsPerBlock - 1) / kGainRowsPerBlock), dim3(256), 0, s,
+                       params, refs, gain);
     return hipGetLastError();
 }
 
