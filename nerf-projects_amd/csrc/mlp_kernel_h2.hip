@@ -777,7 +777,9 @@ __global__ __launch_bounds__(256) void layer_gain_kernel(const float* params, co
 __global__ __launch_bounds__(1024) void equalise_rows_kernel(const float* params, const EqualiseRefs r, float* out) {
     __shared__ int expo[kMaxLinears][256];    // e_j of every linear (0 where rows are not scaled)
     __shared__ int row_exp[256];              // binade of a row's norm, -1000: leave the row alone
-    __shared__ int median_exp;
+    constexpr int kExpBins = 320;             // frexp exponents of finite floats lie within -148 .. 128
+    __shared__ int hist[kExpBins];
+    __shared__ int median_exp, n_valid;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     for (int idx = 0; idx < r.n; ++idx) {
         const int k = r.order[idx];
@@ -811,19 +813,24 @@ __global__ __launch_bounds__(1024) void equalise_rows_kernel(const float* params
             __syncthreads();
             // towards the MEDIAN binade, not the largest: the ordinary units keep their scale - a skip layer concatenates
             // them with gamma(x), whose entries are not scaled, and one huge row must not push 255 others 2^20 above those
-            if (threadIdx.x == 0) median_exp = 0;
+            // (a histogram over the binades a float's norm can have, walked by one thread)
+            for (int q = threadIdx.x; q < kExpBins; q += blockDim.x) hist[q] = 0;
+            if (threadIdx.x == 0) n_valid = 0;
             __syncthreads();
-            for (int j = threadIdx.x; j < n_out; j += blockDim.x) {
-                const int mine = row_exp[j];
-                if (mine <= -1000) continue;
-                int less = 0, leq = 0, valid = 0;
-                for (int q = 0; q < n_out; ++q) {
-                    const int o = row_exp[q];
-                    valid += o > -1000;
-                    less += o > -1000 && o < mine;
-                    leq += o > -1000 && o <= mine;
+            for (int j = threadIdx.x; j < n_out; j += blockDim.x)
+                if (row_exp[j] > -1000) {
+                    const int q = row_exp[j] + kExpBins / 2;
+                    atomicAdd(&hist[q < 0 ? 0 : (q >= kExpBins ? kExpBins - 1 : q)], 1);
+                    atomicAdd(&n_valid, 1);
                 }
-                if (less <= valid / 2 && valid / 2 < leq) median_exp = mine;      // (every such thread writes the same value)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int q = 0, seen = 0;
+                for (; q < kExpBins; ++q) {
+                    seen += hist[q];
+                    if (seen > n_valid / 2) break;       // the smallest binade with more than half of the rows at or below it
+                }
+                median_exp = n_valid > 0 ? q - kExpBins / 2 : 0;
             }
             __syncthreads();
             for (int j = threadIdx.x; j < n_out; j += blockDim.x) {
