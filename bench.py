@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Benchmark of the NeRF ray-chunk renderer on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Both forms work for any N. Called plainly with N > 1 (or with --force-collective), bench.py starts the second form
+itself as a CHILD process - before this process has touched the GPU - relays the child's output and exits with its
+return code (self_launch_command below).
 
 One *step* = one pass of the hot path over one frame of synthetic rays: the 800x800 Blender-lego
 camera at 64 coarse + 128 fine samples (BASELINE.json configs[2]; configs[3] is the same frame over
@@ -66,6 +72,35 @@ def parse():
     p.add_argument("--force-collective", action="store_true",
                    help="under torch.distributed.run with one rank: still create the RCCL group and gather")
     return p.parse_args()
+
+
+def self_launch_command(argv, n_gpus, port=None):
+    """The torch.distributed.run command line a plain `python bench.py --gpus N ...` turns into (one rank per GPU of this
+    node over RCCL; 127.0.0.1 because a container's hostname may not resolve)."""
+    if port is None:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args):
+    """Run this benchmark under torch.distributed.run as a child process and return its exit code. Nothing in this
+    process has initialised the GPU (module-level `import torch` does not), so the hop is an ordinary subprocess - never an
+    exec - and the child's ranks are the only processes on the devices."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this host driver
+    env["NERF_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = self_launch_command(sys.argv[1:], args.gpus)
+    print("bench.py: not under torch.distributed.run; starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:                                 # relay as it comes: the contract line is rank 0's stdout
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def cpu_baseline(sample_rays, sd_c, sd_f, Sc, Si, white, target_s):
@@ -220,9 +255,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.force_collective):
+        # plain `python bench.py --gpus N`: become the launcher (before any GPU call) instead of asking for one
+        if os.environ.get("NERF_BENCH_SELF_LAUNCHED"):
+            raise SystemExit("bench.py: the launcher did not set WORLD_SIZE")
+        raise SystemExit(self_launch(args))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     use_dist = world > 1 or (args.force_collective and "RANK" in os.environ)
@@ -349,6 +387,7 @@ def main():
                      "vs_f32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS}
         out = {
             "metric": "ray_samples_per_sec", "value": value, "unit": "ray-samples/s", "n_gpus": world,
+            "n_ranks_seen": dist.get_world_size() if use_dist else 1,      # what the process group itself reports
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": arith["dtype"],
             "data": "synthetic",

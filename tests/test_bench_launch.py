@@ -1,0 +1,79 @@
+"""bench.py's launch forms (CPU): called plainly with --gpus N > 1 it must turn itself into the torch.distributed.run
+command line the driver would have used - as a child process, before anything touches the GPU - instead of exiting with
+a usage message; under torch.distributed.run it must not hop again."""
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def bench():
+    spec = importlib.util.spec_from_file_location("_bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_gpus_8_builds_the_drivers_command(bench):
+    cmd = bench.self_launch_command(["--gpus", "8", "--steps", "5", "--warmup", "2"], 8, port=29511)
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29511"
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[script + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]      # the caller's arguments, unchanged
+    # a free port is picked when none is given
+    auto = bench.self_launch_command([], 2)
+    assert 1024 <= int(auto[auto.index("--master-port") + 1]) <= 65535
+
+
+@pytest.mark.parametrize("argv", [["--gpus", "8"], ["--gpus", "2", "--steps", "1"], ["--gpus", "1", "--force-collective"]])
+def test_plain_call_hops_before_any_gpu_use(bench, monkeypatch, argv):
+    """No WORLD_SIZE in the environment: main() hands over to self_launch and exits with the child's code; it neither
+    selects a device nor creates a process group first."""
+    import torch
+    seen = {}
+
+    def fake_launch(args):
+        seen["gpus"] = args.gpus
+        return 37
+
+    def forbidden(*a, **k):
+        raise AssertionError("the GPU / process group was touched before the hop")
+
+    for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NERF_BENCH_SELF_LAUNCHED"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setattr(bench, "self_launch", fake_launch)
+    monkeypatch.setattr(torch.cuda, "set_device", forbidden)
+    monkeypatch.setattr(torch.distributed, "init_process_group", forbidden)
+    monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 37 and seen["gpus"] == int(argv[1])
+
+
+def test_no_second_hop_under_the_launcher(bench, monkeypatch):
+    """With WORLD_SIZE set (torch.distributed.run started us) a mismatch is an error, never another launch."""
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setattr(bench, "self_launch", lambda args: pytest.fail("hopped again"))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(e.value.code)
+
+
+def test_self_launch_relays_output_and_exit_code(bench, monkeypatch, capfd):
+    """The hop itself, with a stand-in command: stdout is relayed line by line and the child's return code comes back."""
+    import argparse
+    monkeypatch.setattr(bench, "self_launch_command",
+                        lambda argv, n, port=None: [sys.executable, "-c", "import sys; print('{\"metric\": 1}'); sys.exit(5)"])
+    rc = bench.self_launch(argparse.Namespace(gpus=2))
+    out = capfd.readouterr().out
+    assert rc == 5 and '{"metric": 1}' in out

@@ -875,6 +875,29 @@ def test_bench_under_torchrun_with_rccl_group(N):
     d = json.loads(line)
     assert d["metric"] == "ray_samples_per_sec" and d["n_gpus"] == 1 and d["value"] > 1e7
     assert d["config"]["workload"] == "lego_400x400_64c" and d["roofline"]["frac"] > 0.3
+    assert d["n_ranks_seen"] == 1
+
+
+def test_bench_plain_call_launches_itself(N):
+    """`python bench.py --gpus 1 --force-collective` with no launcher in the environment - the shape of the driver's N = 1
+    command, and of a by-hand `--gpus 8`: bench.py starts torch.distributed.run as a child before it touches the GPU and
+    relays the child's contract line and return code (tests/test_bench_launch.py checks the command line on the CPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NERF_BENCH_SELF_LAUNCHED")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-collective", "--steps", "1", "--warmup",
+           "0", "--no-cpu-baseline", "--no-other-precision", "--workload", "lego_400x400_64c"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "torch.distributed.run" in out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["metric"] == "ray_samples_per_sec" and d["n_gpus"] == 1 and d["n_ranks_seen"] == 1 and d["value"] > 1e7
+    assert d["config"]["parallelism"] == "single GPU"
 
 
 # ---- training step (section 8 f3) vs the reference's autograd + torch.optim.Adam ------------------------
