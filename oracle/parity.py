@@ -59,7 +59,7 @@ def check_resampled(got, want, injected=None, fp64=None, foreground=None):
        sample positions: deterministic, and it is what explains each flip below - the only input of the fine pass
        that differs in the free-running render is the depth vector.
     2. free-running ``got``: a ray is a *flip* if rgb or acc is off by > 1e-4 (or disp by > 1e-3 relative). The number of
-       flips must not exceed 3x the number the reference produces against its own fp64 evaluation on the same rays
+       flips must not exceed 2x the number the reference produces against its own fp64 evaluation on the same rays
        (``fp64``; at least 1, the resolution of a count).
     3. z_std of the non-flip rays within 3x the reference's own fp32-vs-fp64 maximum (at least 1e-4).
 
@@ -94,8 +94,10 @@ def check_resampled(got, want, injected=None, fp64=None, foreground=None):
             z_tol = max(z_tol, float(np.abs(w["z_std"] - w64["z_std"])[~rf].max()))
     stats["flips"] = int(flips.sum())
     stats["flip_rays"] = np.flatnonzero(flips)
-    assert flips.sum() <= 3 * ref_flips, (f"{int(flips.sum())} rays moved by more than 1e-4; the reference moves "
-                                          f"{ref_flips} against its own fp64 render", err["rgb"][flips])
+    # (measured on the bench frame: 7 flips against the reference's own 6)
+    assert flips.sum() <= 2 * ref_flips, (f"flips={int(flips.sum())} rays moved by more than 1e-4; "
+                                          f"reference_fp32_vs_fp64_flips={ref_flips} (the reference against its own fp64 "
+                                          f"render of the same rays); allowed 2x", err["rgb"][flips])
     if "z_std" in g and "z_std" in w:
         ez = np.abs(g["z_std"] - w["z_std"])[~flips]
         assert ez.max() <= 3 * z_tol, ("z_std of the non-flip rays", ez.max(), z_tol)
