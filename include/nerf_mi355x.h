@@ -9,8 +9,9 @@
  * names and signatures, and INTEGRATION.md shows the stub a maintainer would add.
  *
  * Conventions
- *   - Every function returns 0 on success or a negative NERF_E_* code;
- *     nerf_last_error() returns a thread-local message for the last failure.
+ *   - Every function returns 0 on success, a negative NERF_E_* code on failure, or a positive
+ *     NERF_W_* warning (work done, outputs valid); nerf_last_error() returns a thread-local
+ *     message for the last failure or warning.
  *   - Pointers marked [dev] are device (HBM) addresses on the context's GPU; [host]
  *     are ordinary host addresses. All arrays are dense row-major fp32.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream). Calls
@@ -43,6 +44,9 @@ extern "C" {
 #define NERF_E_HIP (-2)         /* a HIP runtime call failed                */
 #define NERF_E_STATE (-3)       /* e.g. weights of a slot not loaded        */
 #define NERF_E_NOMEM (-4)
+/* Positive codes are warnings: the call did its work and the outputs are valid (see "Precision guard" below). */
+#define NERF_W_PRECISION 1            /* the fp16-pair kernel's scale bound was loose in this call; outputs are its own   */
+#define NERF_W_PRECISION_FALLBACK 2   /* ... and the work was redone (frame) / is being done from now on (training) in fp32 */
 
 #define NERF_MAX_SKIPS 8
 #define NERF_SLOT_COARSE 0      /* network_fn   (nerf.ipynb:887-889) */
@@ -114,6 +118,25 @@ int nerf_get_precision(nerf_ctx* ctx);
  * counter. 0 on every network trained or initialised like a NeRF; non-zero means: compare with NERF_PRECISION_F32 on
  * these weights (rows of large weights that cancel). */
 int nerf_precision_status(nerf_ctx* ctx, int64_t* loose_bound_events, int reset);
+/* Precision guard: how that counter reaches the caller without being asked for. The reference evaluates the network in
+ * fp32 (nerf/nerf.py:57-111 under torch.float32, nerf.ipynb:76), so a loose bound must not pass silently:
+ *   nerf_render_frame / nerf_render_shard   args->precision_guard: NERF_GUARD_OFF enqueue and return as before;
+ *                        NERF_GUARD_REPORT synchronise the stream at the end and return NERF_W_PRECISION if events were
+ *                        counted during the frame; NERF_GUARD_FALLBACK additionally render the range again with the fp32
+ *                        kernel and return NERF_W_PRECISION_FALLBACK (the Python mirror's render() does this).
+ *   nerf_render_rays     stays asynchronous; it enqueues a 4-byte copy of the counter to a pinned host mirror behind its
+ *                        kernels. nerf_precision_peek reads the mirror WITHOUT synchronising (events of completed work that
+ *                        have not been reported yet); nerf_precision_check synchronises `stream` first. Both mark what
+ *                        they return as reported. The Python mirror peeks on entry of render_rays() and checks at the end
+ *                        of batchify_rays(), which re-renders the chunks in fp32 when the check is positive.
+ *   nerf_train_step      peeks on entry: if events of an earlier step have become visible the context's TRAINING switches
+ *                        to the fp32 kernels from this step on (until nerf_set_precision is called again) and the call
+ *                        returns NERF_W_PRECISION_FALLBACK once. */
+#define NERF_GUARD_OFF 0
+#define NERF_GUARD_REPORT 1
+#define NERF_GUARD_FALLBACK 2
+int nerf_precision_peek(nerf_ctx* ctx, int64_t* new_events);
+int nerf_precision_check(nerf_ctx* ctx, void* stream, int64_t* new_events);
 
 /* Weights ---------------------------------------------------------------------------
  * Replaces NeRF.__init__ + load_state_dict (nerf/nerf.py:9-55; checkpoint reload at
@@ -267,6 +290,7 @@ typedef struct nerf_frame_args {
     float* acc0;
     float* z_std;
     void* stream;
+    int32_t precision_guard;    /* NERF_GUARD_* (see "Precision guard"); 0 = none: the call only enqueues  */
 } nerf_frame_args;
 
 int nerf_render_frame(nerf_ctx* ctx, const nerf_frame_args* args);

@@ -19,8 +19,10 @@ EXPORTS = (
     "nerf_workspace_bytes", "nerf_generate_rays", "nerf_image_metrics", "nerf_train_step", "nerf_get_weights",
     "nerf_get_gradients", "nerf_stratified_z", "nerf_resample", "nerf_render_frame", "nerf_set_precision",
     "nerf_get_precision", "nerf_precision_status", "nerf_get_adam_state", "nerf_set_adam_state",
-    "nerf_shard_bounds", "nerf_render_shard",
+    "nerf_shard_bounds", "nerf_render_shard", "nerf_precision_peek", "nerf_precision_check",
 )
+NERF_W_PRECISION, NERF_W_PRECISION_FALLBACK = 1, 2
+NERF_GUARD_OFF, NERF_GUARD_REPORT, NERF_GUARD_FALLBACK = 0, 1, 2
 
 
 class NerfArch(C.Structure):
@@ -64,7 +66,7 @@ class FrameArgs(C.Structure):
                 ("N_samples", C.c_int32), ("N_importance", C.c_int32), ("slot_coarse", C.c_int32),
                 ("slot_fine", C.c_int32), ("lindisp", C.c_int32), ("white_bkgd", C.c_int32), ("rgb_map", _FP),
                 ("disp_map", _FP), ("acc_map", _FP), ("rgb0", _FP), ("disp0", _FP), ("acc0", _FP), ("z_std", _FP),
-                ("stream", C.c_void_p)]
+                ("stream", C.c_void_p), ("precision_guard", C.c_int32)]
 
 
 _lib = None
@@ -147,12 +149,21 @@ def load():
     lib.nerf_set_adam_state.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), i32]
     lib.nerf_precision_status.restype = i32
     lib.nerf_precision_status.argtypes = [vp, C.POINTER(i64), i32]
+    lib.nerf_precision_peek.restype = i32
+    lib.nerf_precision_peek.argtypes = [vp, C.POINTER(i64)]
+    lib.nerf_precision_check.restype = i32
+    lib.nerf_precision_check.argtypes = [vp, vp, C.POINTER(i64)]
     _lib = lib
     return lib
 
 
 def check(rc):
-    """Preserve the reference's exception convention: errors are Python exceptions."""
-    if rc != 0:
+    """Preserve the reference's exception convention: errors (negative codes) are Python exceptions. Positive codes are
+    the library's warnings (NERF_W_*: the work was done); they become RuntimeWarnings and are returned."""
+    if rc < 0:
         msg = load().nerf_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"nerf_mi355x error {rc}: {msg}")
+    if rc > 0:
+        import warnings
+        warnings.warn(load().nerf_last_error().decode("utf-8", "replace"), RuntimeWarning, stacklevel=3)
+    return rc

@@ -94,6 +94,19 @@ int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net_in, int mode, hipStr
 }  // namespace
 
 namespace nerf {
+// Precision guard: the counter of loose scale bounds follows the work of this call to the pinned host mirror.
+hipError_t mirror_loose(nerf_ctx* c, hipStream_t s) {
+    if (c->precision != NERF_PRECISION_F16X2 || !c->h_loose) return hipSuccess;
+    return hipMemcpyAsync(c->h_loose, c->d_loose, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+}
+// events in the mirror that no call has reported yet; marks them reported
+unsigned take_new_loose(nerf_ctx* c) {
+    const unsigned v = c->h_loose ? *(volatile unsigned*)c->h_loose : 0u;
+    const unsigned n = v - c->loose_seen;      // (the counter only grows between resets; a reset zeroes both)
+    c->loose_seen = v;
+    return n;
+}
+
 EqualiseRefs equalise_refs(const nerf_arch& a, const std::vector<LinearDesc>& linears) {
     EqualiseRefs r{};
     const int D = a.D, W = a.W;
@@ -263,6 +276,8 @@ int nerf_ctx_create(int device, nerf_ctx** out) {
         DeviceGuard g(device);
         hipError_t e2 = hipMalloc((void**)&c->d_loose, sizeof(unsigned));
         if (e2 == hipSuccess) e2 = hipMemset(c->d_loose, 0, sizeof(unsigned));
+        if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&c->h_loose, sizeof(unsigned), hipHostMallocDefault);
+        if (e2 == hipSuccess) *c->h_loose = 0u;
         if (e2 != hipSuccess) {
             set_error("nerf_ctx_create: device allocation failed: %s", hipGetErrorString(e2));
             delete c;
@@ -281,6 +296,7 @@ void nerf_ctx_destroy(nerf_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->frame_rays) (void)hipFree(c->frame_rays);
     if (c->d_loose) (void)hipFree(c->d_loose);
+    if (c->h_loose) (void)hipHostFree(c->h_loose);
     if (c->scratch_done) (void)hipEventDestroy(c->scratch_done);
     for (auto& p : c->events) {
         (void)hipEventDestroy(p.first);
@@ -296,6 +312,7 @@ int nerf_set_precision(nerf_ctx* c, int precision) {
         return NERF_E_INVALID;
     }
     c->precision = precision;
+    c->train_force_f32 = false;      // an explicit choice ends a fallback of the training path (nerf_train_step)
     return NERF_OK;
 }
 
@@ -453,7 +470,9 @@ int nerf_mlp_forward(nerf_ctx* c, int slot, const float* x, int64_t B, float* ou
     a.x = x;
     a.x_ld = net->arch.input_ch + net->arch.input_ch_views;
     a.out = out;
-    return run_mlp(c, a, *net, kInputEmbedded, (hipStream_t)stream);
+    const int rc = run_mlp(c, a, *net, kInputEmbedded, (hipStream_t)stream);
+    if (rc == NERF_OK) HIP_TRY(mirror_loose(c, (hipStream_t)stream));
+    return rc;
 }
 
 int nerf_run_network(nerf_ctx* c, int slot, const float* pts, const float* viewdirs, int64_t n_rays,
@@ -476,7 +495,9 @@ int nerf_run_network(nerf_ctx* c, int slot, const float* pts, const float* viewd
     a.pts = pts;
     a.viewdirs = net->arch.use_viewdirs ? viewdirs : nullptr;
     a.out = out;
-    return run_mlp(c, a, *net, kInputPoints, (hipStream_t)stream);
+    const int rc = run_mlp(c, a, *net, kInputPoints, (hipStream_t)stream);
+    if (rc == NERF_OK) HIP_TRY(mirror_loose(c, (hipStream_t)stream));
+    return rc;
 }
 
 int nerf_raw2outputs(nerf_ctx* c, const float* raw, int C, const float* z_vals, const float* rays_d,
@@ -645,7 +666,9 @@ int nerf_render_rays(nerf_ctx* c, const nerf_render_args* r) {
     DeviceGuard g(c->device);
     ScratchScope scope(c, (hipStream_t)r->stream);
     HIP_TRY(scope.status);
-    return render_rays_locked(c, r);
+    const int rc = render_rays_locked(c, r);
+    if (rc == NERF_OK) HIP_TRY(mirror_loose(c, (hipStream_t)r->stream));
+    return rc;
 }
 
 int nerf_generate_rays(nerf_ctx* c, const nerf_camera* cam, int64_t first_pixel, int64_t n_pixels, float* rays,
@@ -697,6 +720,7 @@ int nerf_render_frame(nerf_ctx* c, const nerf_frame_args* f) {
         HIP_TRY(hipMalloc((void**)&c->frame_rays, (size_t)per * ld * sizeof(float)));
         c->frame_rays_floats = (size_t)per * ld;
     }
+    auto body = [&]() -> int {
     for (int64_t off = 0; off < f->n_pixels; off += chunk) {
         const int64_t n = off + chunk <= f->n_pixels ? chunk : f->n_pixels - off;
         // stream order makes reusing the one ray buffer safe: chunk k+1's generation runs after chunk k's kernels
@@ -724,6 +748,32 @@ int nerf_render_frame(nerf_ctx* c, const nerf_frame_args* f) {
         if (rc != NERF_OK) return rc;
     }
     return NERF_OK;
+    };
+    int rc = body();
+    if (rc != NERF_OK) return rc;
+    HIP_TRY(mirror_loose(c, s));
+    if (f->precision_guard == NERF_GUARD_OFF || c->precision != NERF_PRECISION_F16X2) return NERF_OK;
+    if (f->precision_guard != NERF_GUARD_REPORT && f->precision_guard != NERF_GUARD_FALLBACK) {
+        set_error("nerf_render_frame: precision_guard %d is not a NERF_GUARD_* value", f->precision_guard);
+        return NERF_E_INVALID;
+    }
+    // the guard: wait for the frame, look at the counter (mirrored behind the frame's kernels)
+    HIP_TRY(hipStreamSynchronize(s));
+    const unsigned n_new = take_new_loose(c);
+    if (n_new == 0) return NERF_OK;
+    if (f->precision_guard == NERF_GUARD_REPORT) {
+        set_error("nerf_render_frame: the fp16-pair kernel's output-scale bound was loose in %u (wavefront, layer) cases "
+                  "of this frame: some activations kept fewer than 24 bits with these weights (NERF_PRECISION_F32 renders "
+                  "them as the reference does)", n_new);
+        return NERF_W_PRECISION;
+    }
+    c->precision = NERF_PRECISION_F32;
+    rc = body();
+    c->precision = NERF_PRECISION_F16X2;
+    if (rc != NERF_OK) return rc;
+    set_error("nerf_render_frame: the fp16-pair kernel's output-scale bound was loose in %u (wavefront, layer) cases of "
+              "this frame; the range was rendered again with the fp32 kernel", n_new);
+    return NERF_W_PRECISION_FALLBACK;
 }
 
 int nerf_shard_bounds(int64_t n_total, int world, int rank, int64_t* first_pixel, int64_t* n_pixels) {
@@ -815,8 +865,33 @@ int nerf_precision_status(nerf_ctx* c, int64_t* loose_bound_events, int reset) {
     unsigned v = 0;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(&v, c->d_loose, sizeof(v), hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(c->d_loose, 0, sizeof(v)));
+    if (reset) {
+        HIP_TRY(hipMemset(c->d_loose, 0, sizeof(v)));
+        if (c->h_loose) *c->h_loose = 0u;
+        c->loose_seen = 0u;
+    }
     *loose_bound_events = (int64_t)v;
+    return NERF_OK;
+}
+
+int nerf_precision_peek(nerf_ctx* c, int64_t* new_events) {
+    if (!c || !new_events) {
+        set_error("nerf_precision_peek: NULL argument");
+        return NERF_E_INVALID;
+    }
+    *new_events = (int64_t)take_new_loose(c);
+    return NERF_OK;
+}
+
+int nerf_precision_check(nerf_ctx* c, void* stream, int64_t* new_events) {
+    if (!c || !new_events) {
+        set_error("nerf_precision_check: NULL argument");
+        return NERF_E_INVALID;
+    }
+    DeviceGuard g(c->device);
+    HIP_TRY(mirror_loose(c, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    *new_events = (int64_t)take_new_loose(c);
     return NERF_OK;
 }
 

@@ -22,6 +22,12 @@ struct nerf_ctx {
     int precision = NERF_PRECISION_F16X2;   // arithmetic of the fused MLP kernel (nerf_set_precision)
     nerf::PackedNet nets[NERF_NUM_SLOTS];
     unsigned* d_loose = nullptr;   // see nerf_precision_status
+    // The precision guard (nerf_mi355x.h, "Precision guard"): a pinned host mirror of d_loose, refreshed by a 4-byte copy
+    // enqueued behind every render / training call, so that a later call can see - without synchronising - whether the
+    // fp16-pair kernel's scale bound was loose in work that has completed; `loose_seen` is the count already reported.
+    unsigned* h_loose = nullptr;
+    unsigned loose_seen = 0;
+    bool train_force_f32 = false;  // set by nerf_train_step when it sees new events: training continues on the fp32 kernels
     char* ws = nullptr;          // workspace arena
     size_t ws_bytes = 0;
     float* frame_rays = nullptr;   // ray record of the chunk being rendered by nerf_render_frame
@@ -43,6 +49,9 @@ struct nerf_ctx {
 };
 
 namespace nerf {
+
+hipError_t mirror_loose(nerf_ctx* c, hipStream_t s);     // api.cpp: the precision guard's counter mirror
+unsigned take_new_loose(nerf_ctx* c);
 
 struct DeviceGuard {
     int prev = -1;

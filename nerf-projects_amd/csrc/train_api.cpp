@@ -540,6 +540,14 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     ScratchScope scope(c, s);
     HIP_TRY(scope.status);
     int rc;
+    // Precision guard (nerf_mi355x.h): events counted by work that has completed since the last look - earlier steps of
+    // this loop, typically - move the training path to the fp32 kernels, from this step on and until nerf_set_precision
+    bool fell_back = false;
+    if (c->precision == NERF_PRECISION_F16X2 && !c->train_force_f32 && take_new_loose(c) > 0) {
+        c->train_force_f32 = true;
+        fell_back = true;
+    }
+    const int precision = c->train_force_f32 ? NERF_PRECISION_F32 : c->precision;
     for (PackedNet* n : {&nc, &nf}) {
         const bool fresh = !n->train.ready;
         if ((rc = ensure_train_state(c, *n))) return rc;
@@ -575,7 +583,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     pc.P = Pc;
     pc.S = Sc;
     pc.fused_backward = !gemm_backward_requested() && nc.train.d_stream_bwd != nullptr && nc.out_ch == 4;
-    pc.precision = c->precision;
+    pc.precision = precision;
     pc.loose = c->d_loose;
     carve_pass(ar, pc);
     Pass pf;
@@ -585,7 +593,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
         pf.P = Pf;
         pf.S = Sf;
         pf.fused_backward = !gemm_backward_requested() && nf.train.d_stream_bwd != nullptr && nf.out_ch == 4;
-        pf.precision = c->precision;
+        pf.precision = precision;
         pf.loose = c->d_loose;
         carve_pass(ar, pf);
     }
@@ -638,6 +646,12 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
             if ((rc = refresh_derived(*n, s))) return rc;
             if (!Si || shared) break;
         }
+    }
+    HIP_TRY(mirror_loose(c, s));
+    if (fell_back) {
+        set_error("nerf_train_step: the fp16-pair kernels' output-scale bound was loose in an earlier step (some activations "
+                  "kept fewer than 24 bits with these weights); training continues on the fp32 kernels");
+        return NERF_W_PRECISION_FALLBACK;
     }
     return NERF_OK;
 }

@@ -63,6 +63,19 @@ class Context:
         check(self.lib.nerf_precision_status(self.handle, C.byref(n), int(bool(reset))))
         return n.value
 
+    def precision_peek(self):
+        """Loose-bound events of COMPLETED work that no call has reported yet (no synchronisation: a pinned mirror of the
+        counter follows every render / training call). Marks them reported."""
+        n = C.c_int64()
+        check(self.lib.nerf_precision_peek(self.handle, C.byref(n)))
+        return n.value
+
+    def precision_check(self):
+        """The same after waiting for the current stream: events of everything enqueued so far."""
+        n = C.c_int64()
+        check(self.lib.nerf_precision_check(self.handle, self.stream(), C.byref(n)))
+        return n.value
+
     def get_precision(self):
         code = self.lib.nerf_get_precision(self.handle)
         return {v: k for k, v in self.PRECISIONS.items()}[code]
@@ -89,6 +102,22 @@ class Context:
 
     def workspace_bytes(self):
         return int(self.lib.nerf_workspace_bytes(self.handle))
+
+
+_LOOSE = ("the fp16-pair MLP kernel's output-scale bound was loose in {n} (wavefront, layer) cases, i.e. some activations "
+          "kept fewer than 24 bits with these weights")
+
+
+def _peek_precision(ctx, where):
+    """Entry of an asynchronous call: report (never hide) what completed work has counted since the last look."""
+    if ctx.get_precision() != "f16x2":
+        return 0
+    n = ctx.precision_peek()
+    if n:
+        import warnings
+        warnings.warn(f"{where}: in earlier calls " + _LOOSE.format(n=n) + "; get_context().set_precision('f32') "
+                      "evaluates them as the reference does", RuntimeWarning, stacklevel=3)
+    return n
 
 
 def _warn_if_scale_bound_was_loose(ctx, where):
@@ -564,6 +593,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     if not isinstance(network_fn, NeRF):
         raise TypeError("render_rays needs this package's NeRF for network_fn (no PyTorch fallback exists)")
     ctx = network_fn.ctx
+    _peek_precision(ctx, "render_rays")
     ray_batch = _dev(ray_batch, ctx)
     if ray_batch.dim() != 2 or ray_batch.shape[-1] not in (8, 11):
         raise RuntimeError(f"ray_batch must be [N, 8|11], got {tuple(ray_batch.shape)}")
@@ -638,12 +668,31 @@ def _render_rays_staged(ctx, ray_batch, network_fn, query, Sc, Si, network_fine,
 
 def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
     """nerf.ipynb:514-548."""
-    all_ret = {}
-    for i in range(0, rays_flat.shape[0], chunk):
-        ret = render_rays(rays_flat[i:i + chunk], **kwargs)
-        for k in ret:
-            all_ret.setdefault(k, []).append(ret[k])
-    return {k: torch.cat(all_ret[k], dim=0) for k in all_ret}
+    def run():
+        all_ret = {}
+        for i in range(0, rays_flat.shape[0], chunk):
+            ret = render_rays(rays_flat[i:i + chunk], **kwargs)
+            for k in ret:
+                all_ret.setdefault(k, []).append(ret[k])
+        return {k: torch.cat(all_ret[k], dim=0) for k in all_ret}
+
+    out = run()
+    # Precision guard: the reference evaluates the network in fp32 (nerf.ipynb:76). If the fp16-pair kernel counted a loose
+    # scale bound on these rays, they are rendered again by the fp32 kernel - one 4-byte read behind the last chunk.
+    net = kwargs.get('network_fn')
+    ctx = getattr(net, 'ctx', None)
+    if out and ctx is not None and ctx.get_precision() == "f16x2":
+        n = ctx.precision_check()
+        if n:
+            import warnings
+            warnings.warn("batchify_rays: " + _LOOSE.format(n=n) + "; these rays were rendered again with the fp32 kernel",
+                          RuntimeWarning, stacklevel=2)
+            ctx.set_precision("f32")
+            try:
+                out = run()
+            finally:
+                ctx.set_precision("f16x2")
+    return out
 
 
 # ----------------------------------------------------------------------------------------------
@@ -779,6 +828,7 @@ def _render_frame_fused(ctx, cam, first_pixel, n_pixels, chunk, net_c, net_f, N_
                    acc0=torch.empty((n_pixels,), **o), z_std=torch.empty((n_pixels,), **o))
         f.rgb0, f.disp0, f.acc0, f.z_std = (ret[k].data_ptr() for k in ("rgb0", "disp0", "acc0", "z_std"))
     f.stream = ctx.stream().value
+    f.precision_guard = _lib.NERF_GUARD_FALLBACK      # a frame whose scale bound was loose comes back from the fp32 kernel
     if shard is not None:
         check(ctx.lib.nerf_render_shard(ctx.handle, C.byref(f), int(shard[0]), int(shard[1]), None, None))
     else:
