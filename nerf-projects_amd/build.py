@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnerf_mi355x.so")
-SOURCES = ["api.cpp", "train_api.cpp", "pack_weights.cpp", "mlp_kernel.hip", "mlp_kernel_h2.hip", "ray_kernels.hip",
-           "train_kernels.hip", "train_dw_kernel.hip"]
+SOURCES = ["api.cpp", "train_api.cpp", "pack_weights.cpp", "mlp_kernel.hip", "mlp_kernel_h2.hip", "mlp_bwd_kernel_h2.hip",
+           "ray_kernels.hip", "train_kernels.hip", "train_dw_kernel.hip"]
 HEADERS = [os.path.join(CSRC, "nerf_internal.h"), os.path.join(CSRC, "ctx_internal.h"),
            os.path.join(CSRC, "mlp_inputs.h"), os.path.join(CSRC, "mlp_pair_common.h"),
            os.path.join(ROOT, "include", "nerf_mi355x.h")]
@@ -30,7 +30,7 @@ FLAGS = [
 # The fp16-pair kernel holds 128 accumulators + 176 operand registers and needs the AGPR half for the former.
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 # train_dw_kernel.hip: 256 accumulators per lane, likewise.
-EXTRA = {"mlp_kernel_h2.hip": [], "train_dw_kernel.hip": []}
+EXTRA = {"mlp_kernel_h2.hip": [], "mlp_bwd_kernel_h2.hip": [], "train_dw_kernel.hip": []}
 
 
 def hipcc():

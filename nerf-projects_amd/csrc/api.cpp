@@ -35,6 +35,10 @@ int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net_in, int mode, hipStr
         const int rc = refresh_h2(net, s);          // the weights have been trained since the last fp16-pair launch
         if (rc != NERF_OK) return rc;
     }
+    if (c->precision != NERF_PRECISION_F16X2 && net.f32_dirty) {
+        const int rc = refresh_f32(net, s);
+        if (rc != NERF_OK) return rc;
+    }
     a.stream = net.d_stream;
     a.stream_h2 = net.d_stream_h2;
     a.descale = net.d_descale;
@@ -148,14 +152,25 @@ EqualiseRefs equalise_refs(const nerf_arch& a, const std::vector<LinearDesc>& li
     return r;
 }
 
+int refresh_f32(PackedNet& net, hipStream_t s) {
+    HIP_TRY(launch_gather(net.d_params, net.train.d_stream_table, (int64_t)net.stream_table.size(), net.d_stream, s));
+    HIP_TRY(launch_gather(net.d_params, net.train.d_bias_table, (int64_t)net.bias_table.size(), net.d_bias, s));
+    net.f32_dirty = false;
+    return NERF_OK;
+}
+
 int refresh_h2(PackedNet& net, hipStream_t s) {
-    HIP_TRY(launch_equalise_rows(net.d_params, equalise_refs(net.arch, net.linears), net.d_params_eq, s));
+    // the exponents are chosen afresh at load time and every kEqualiseEvery optimiser steps; in between they are re-applied
+    const bool reuse = net.eq_age > 0 && net.eq_age < kEqualiseEvery;
+    HIP_TRY(launch_equalise_rows(net.d_params, equalise_refs(net.arch, net.linears), net.d_params_eq, net.d_row_exp, reuse, s));
+    if (!reuse) net.eq_age = 0;
     HIP_TRY(launch_gather(net.d_params_eq, net.train.d_stream_table, (int64_t)net.stream_table.size(), net.d_stream_eq, s));
     HIP_TRY(launch_gather(net.d_params_eq, net.train.d_bias_table, (int64_t)net.bias_table.size(), net.d_bias_h2, s));
     HIP_TRY(launch_convert_stream_h2(net.d_stream_eq, net.d_chunk_layer, net.n_chunks, net.d_chunk_max, net.d_stream_h2,
                                      net.d_descale, s));
     HIP_TRY(launch_layer_gains(net.d_params_eq, gain_refs(net.arch, net.linears), net.d_gain, s));
     net.h2_dirty = false;
+    if (net.train.bwd_is_eq) net.train.bwd_dirty = true;      // d_params_eq moved (also when only the exponents did)
     return NERF_OK;
 }
 
@@ -180,7 +195,8 @@ void free_net(PackedNet& n) {
                     (void*)n.train.d_v, (void*)n.train.d_wt, (void*)n.train.d_stream_table,
                     (void*)n.train.d_bias_table, (void*)n.train.d_bwd_table, (void*)n.train.d_stream_bwd, (void*)n.d_stream_h2, (void*)n.d_descale, (void*)n.d_chunk_layer,
                     (void*)n.d_chunk_max, (void*)n.d_gain, (void*)n.d_params_eq, (void*)n.d_stream_eq, (void*)n.d_bias_h2,
-                    (void*)n.train.d_stream_h2, (void*)n.train.d_descale, (void*)n.train.d_gain})
+                    (void*)n.d_row_exp, (void*)n.train.d_stream_bwd_h2, (void*)n.train.d_descale_bwd, (void*)n.train.d_gain_bwd,
+                    (void*)n.train.d_chunk_layer_bwd, (void*)n.train.d_chunk_max_bwd})
         if (p) (void)hipFree(p);
     n = PackedNet{};
 }
@@ -418,6 +434,7 @@ int nerf_load_weights(nerf_ctx* c, int slot, const nerf_arch* arch, const float*
     if (e == hipSuccess) e = hipMalloc((void**)&net.d_params_eq, net.n_params * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&net.d_stream_eq, (size_t)nc * kChunkBytes);
     if (e == hipSuccess) e = hipMalloc((void**)&net.d_bias_h2, (size_t)nbt * kBiasTileFloats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&net.d_row_exp, (size_t)kMaxLinears * 256 * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&net.train.d_stream_table, net.stream_table.size() * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&net.train.d_bias_table, net.bias_table.size() * sizeof(int));
     if (e == hipSuccess)

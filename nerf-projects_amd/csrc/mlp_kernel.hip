@@ -632,6 +632,9 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
                 });
             load_tile_at(kept, hid[7], 7);
         }
+        // (the stream carries the alpha row as an MFMA column here for the fp16-pair kernel; this kernel adds the rank-1 term
+        // below and only keeps the ring turning)
+        consume_chunk<8>(pipe, cur, [&](auto, auto, const Frag16&) {});
         if (b.maxes) track_max<8>(b.maxes + kBwdMaxKept + b.D - 1, hid);      // the kept h_{D-1}, before it becomes d z_{D-1}
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -666,7 +669,7 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
 
 hipError_t launch_mlp_bwd(const MlpBwdLaunch& b, hipStream_t s) {
     if (b.n_points <= 0) return hipSuccess;
-    if (b.n_chunks != 12 + 8 * (b.D - 1) || b.C < 4) return hipErrorInvalidValue;
+    if (b.n_chunks != 13 + 8 * (b.D - 1) || b.C < 4) return hipErrorInvalidValue;
     if (b.n_points > (int64_t)1 << 22) return hipErrorInvalidValue;      // 32-bit element offsets in load/store_tiles
     // the hooks inside the chunk loop are unconditional 16-byte accesses (RowRef)
     bool rows_ok = training_rows_ok(b.out.hv, b.out.hv_ld) && training_rows_ok(b.out.feat, b.out.feat_ld) &&

@@ -29,44 +29,6 @@
 
 namespace nerf {
 
-__device__ __forceinline__ f32x16 mma(const f32x4& a, const u32x4& b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
-}
-
-// MFMA K (0..5) of a step, small terms first
-template <int K, bool FIRST>
-__device__ __forceinline__ void mma_one(f32x16& acc, const Frag4& f, const XT& x) {
-#ifdef NERF_MMA_SHARED_OPERANDS
-    // neighbours share an operand: (q0,lo0) (q0,hi0) (q1,hi0) | (q3,hi1) (q2,hi1) (q2,lo1)
-    constexpr int A[6] = {0, 0, 1, 3, 2, 2};
-    constexpr bool LO[6] = {true, false, false, false, false, true};
-#else
-    constexpr int A[6] = {1, 0, 0, 3, 2, 2};
-    constexpr bool LO[6] = {false, true, false, false, true, false};
-#endif
-    constexpr int s = K / 3;
-    const u32x4& b = LO[K] ? x.lo[s] : x.hi[s];
-    if constexpr (K == 0 && FIRST) {
-        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        acc = mma(f.q[A[K]], b, zero);
-    } else {
-        acc = mma(f.q[A[K]], b, acc);
-    }
-}
-
-// max with the partner lane of the other half-wave: v_permlane32_swap on two copies yields (lo, lo) and (hi, hi)
-// - a vector instruction, no trip through the LDS crossbar and no lgkmcnt wait. From inline asm: through
-// __builtin_amdgcn_permlane32_swap(u, u, ...) hipcc folds max(r[0], r[1]) to r[0] (it takes the two results of a swap
-// of equal inputs for equal), which silently made every lane use the LOWER half-wave's value - harmless while both
-// halves of a point have similar maxima, an fp16 overflow (NaN) when one row of the upper half dominates
-// (tests: test_mlp_precisions_vs_fp64, "one row x2^16").
-__device__ __forceinline__ float half_max(float m) {
-    float a = m, b = m;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 // multiply a split tile by 2^d (exact while nothing leaves the fp16 range)
 __device__ __forceinline__ void rescale_tile(XT& x, int d) {
     const _Float16 f = (_Float16)pow2f(d < -30 ? -30 : (d > 15 ? 15 : d));
@@ -83,30 +45,6 @@ __device__ __forceinline__ void rescale_tile(XT& x, int d) {
         }
 }
 
-// ---- LDS reads outside hipcc's LDS-DMA guard ---------------------------------------------------------------
-// hipcc guards every LDS load it can see with s_waitcnt vmcnt(0) while an LDS-DMA write is in flight (it cannot
-// tell the bias block from the ring), which would drain the weight pipeline at every bias read; these reads are
-// issued from inline asm with their own lgkmcnt wait (LDS returns in order, and the waits hipcc computes for its
-// own reads can only become stricter by the extra entries).
-__device__ __forceinline__ unsigned lds_addr(const float* p) {
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
-}
-struct Tile16 {
-    f32x4 q[4];
-};
-__device__ __forceinline__ Tile16 lds_tile_issue(unsigned addr) {
-    Tile16 t;
-    asm volatile(
-        "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
-        "ds_read_b128 %3, %4 offset:48"
-        : "=&v"(t.q[0]), "=&v"(t.q[1]), "=&v"(t.q[2]), "=&v"(t.q[3])
-        : "v"(addr)
-        : "memory");
-    return t;
-}
-__device__ __forceinline__ void lds_tile_wait(Tile16& t) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t.q[0]), "+v"(t.q[1]), "+v"(t.q[2]), "+v"(t.q[3])::"memory");
-}
 // ---- the layer whose raw sums wait to become the next layer's operands -------------------------------------
 // A layer's 8 accumulator tiles are not converted when the layer ends but one tile per chunk of the NEXT layer
 // (which accumulates into the other accumulator set), one register pair per MFMA step, in the shadow of the
@@ -124,6 +62,9 @@ struct Pending {
     float* keep_base;      // STORE kernels: the buffer that keeps this layer's activations for the backward pass ...
     unsigned keep_off;     // ... and this lane's BYTE offset of (its point, feature 4 h) in it
     f32x2 even;            // (convert_pair: the even pair of a register quad, until the odd one completes the 16 bytes)
+    unsigned* mask_base;   // STORE kernels: this layer's ReLU-mask record (MlpStore::mask), this lane's BYTE offset in it,
+    unsigned mask_off;     // and the word being collected (mask_push)
+    unsigned maskw;
 };
 
 // Training forward (STORE kernels): register pair P of tile T of the pending layer - features 32 T + 8 (P/2) + 2 (P%2) + 4 h
@@ -159,11 +100,6 @@ __device__ __forceinline__ void keep_pairs(const Pending& pd, const f32x2& even,
                  : "v"(pd.keep_off), "v"(v), "s"(pd.keep_base), "n"((32 * T + 8 * Q) * 4)
                  : "memory");
 }
-template <int IMM>
-__device__ __forceinline__ void keep_quad(float* base, unsigned off, const f32x4& v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base), "n"(IMM) : "memory");
-}
-
 template <int P, bool STORE = false, int T = 0>
 __device__ __forceinline__ void convert_pair(XT& dst, const f32x16& src, Pending& pd, const f32x2& b) {
 #ifdef NERF_ABLATE_CONV
@@ -185,6 +121,13 @@ __device__ __forceinline__ void convert_pair(XT& dst, const f32x16& src, Pending
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(a1));
     dst.hi[P >> 2][P & 3] = hi;
     dst.lo[P >> 2][P & 3] = lo;
+    if constexpr (STORE) {
+        pd.maskw = mask_push(pd.maskw, hi);
+        if constexpr (P == 7 && (T & 1) == 1) {      // tiles 2w, 2w + 1 done: word w of the record
+            keep_word<4 * (T >> 1)>(pd.mask_base, pd.mask_off, pd.maskw);
+            pd.maskw = 0u;
+        }
+    }
 }
 
 // a whole tile at once (not hidden: tile 0 at the start of a layer)
@@ -250,7 +193,16 @@ __device__ __forceinline__ void chunk_ktile8(PipeH& p, Frag4& cur, f32x16 (&acc)
                 }
             } else if constexpr (pt == 12) conv_slice1(t, pd);
             else if constexpr (pt == 13) conv_slice2<s>(hid[C0], t);
-            else if constexpr (pt == 14 && s < 7) r = lds_pair_issue<128 * C0 + 8 * (s + 1)>(pd.bias_addr);
+            else if constexpr (pt == 14) {
+                if constexpr (s < 7) r = lds_pair_issue<128 * C0 + 8 * (s + 1)>(pd.bias_addr);
+                if constexpr (STORE) {      // the pair's ReLU flags (MlpStore::mask)
+                    pd.maskw = mask_push(pd.maskw, hid[C0].hi[s >> 2][s & 3]);
+                    if constexpr (s == 7 && (C0 & 1) == 1) {
+                        keep_word<4 * (C0 >> 1)>(pd.mask_base, pd.mask_off, pd.maskw);
+                        pd.maskw = 0u;
+                    }
+                }
+            }
         }
     });
 }
@@ -322,6 +274,20 @@ __device__ __forceinline__ void finish_views(f32x16 (&y)[4], const f32x16 (&acc)
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[t][r] = fmaxf(fmaf(acc[t][r], c, b.q[r >> 2][r & 3]), 0.0f);
     }
+}
+
+// the mask word of two fp32 tiles (values >= 0) in mask_push's bit order: value 2s of the first tile at bit 15 - s, 2s + 1
+// at bit 31 - s, the second tile's eight places lower
+__device__ __forceinline__ unsigned relu_mask_word(const f32x16& t0, const f32x16& t1) {
+    unsigned w = 0u;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        w |= (t0[2 * s] > 0.0f ? 1u : 0u) << (15 - s);
+        w |= (t0[2 * s + 1] > 0.0f ? 1u : 0u) << (31 - s);
+        w |= (t1[2 * s] > 0.0f ? 1u : 0u) << (7 - s);
+        w |= (t1[2 * s + 1] > 0.0f ? 1u : 0u) << (23 - s);
+    }
+    return w;
 }
 
 // STORE: the view layer's four output tiles, 16 bytes per instruction
@@ -464,6 +430,10 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             pd.bias_addr = baddr;
             pd.m = 0.0f;
             if constexpr (STORE) {
+                pd.maskw = 0u;
+                // (feature_linear has no ReLU: what its tiles 0, 1 collect goes to the unused third word of the view layer's record)
+                pd.mask_base = is_feature ? a.st.mask_hv + 2 : a.st.mask[l];
+                pd.mask_off = 16u * (2u * (unsigned)pt + (unsigned)h);
                 pd.keep_base = is_feature ? a.st.feat : a.st.h[l];
                 pd.keep_off = 4u * ((unsigned)pt * (unsigned)(is_feature ? a.st.feat_ld : a.st.h_ld[l]) + 4u * (unsigned)h);
 #ifdef NERF_EXP_STORE_BLOCKED  // timing experiment (results are NOT what the backward pass expects): layout blocked by 32 points
@@ -478,8 +448,12 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             }
         };
         // all 8 tiles of the pending layer are converted: its true output range
-        auto close_pending = [&]() {
+        auto close_pending = [&](int slot) {
             m_prev = half_max(pd.m);
+            if constexpr (STORE) {
+                // the largest kept activation of this layer, for the weight-gradient kernel's scale (MlpStore::maxes)
+                enter_max(wave_uniform(a.st.maxes + slot), m_prev, lane);
+            }
             // the scale was chosen for a bound of 2^(10 - t_out); outputs 2^12 and more below it have begun to lose
             // low-half bits (see Pending). Counted, never silent: nerf_precision_status.
             const int slack = 10 - pd.t_out - __builtin_amdgcn_frexp_expf(m_prev);
@@ -503,7 +477,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             chunk_ktile8<6, false, STORE>(pipe, cur, out, hid[5], hid, pend, pd);
             chunk_ktile8<7, false, STORE>(pipe, cur, out, hid[6], hid, pend, pd);
             chunk_ktile8<-1, false>(pipe, cur, out, hid[7], hid, pend, pd);
-            close_pending();
+            close_pending(kBwdMaxKept + l - 1);
             const int t_in = pd.t_out;
             float m_in = m_prev;
             if (a.use_viewdirs && l == a.D) {
@@ -549,7 +523,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             chunk_pair4<4, false, STORE>(pipe, cur, accB, hid[2], hid[3], hid, accA, pd);
             chunk_pair4<6, false, STORE>(pipe, cur, accB, hid[4], hid[5], hid, accA, pd);
             chunk_pair4<-1, false>(pipe, cur, accB, hid[6], hid[7], hid, accA, pd);
-            close_pending();
+            close_pending(kBwdMaxFeatValue);
             XT xd;
             {
                 f32x16 x0, x1, dd;
@@ -567,6 +541,10 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             if constexpr (STORE) {
                 const unsigned off = 4u * ((unsigned)pt * (unsigned)a.st.hv_ld + 4u * (unsigned)h);
                 keep_tiles4<0>(a.st.hv, off, y);
+                // the view layer's ReLU mask in the bit order of the trunk layers' (MlpStore::mask_hv, words 0 and 1)
+                const unsigned moff = 16u * (2u * (unsigned)pt + (unsigned)h);
+                keep_word<0>(a.st.mask_hv, moff, relu_mask_word(y[0], y[1]));
+                keep_word<4>(a.st.mask_hv, moff, relu_mask_word(y[2], y[3]));
             }
             // rgb_linear (nerf.py:101): three rows over the 128-wide view layer
             const float* rb = bias_lds + (8 * a.D + 13) * 32;
@@ -646,6 +624,9 @@ hipError_t launch_mlp_h2(const MlpLaunch& a, int mode, hipStream_t s) {
         };
         bool rows_ok = ok(a.st.feat, a.st.feat_ld) && ok(a.st.hv, a.st.hv_ld);
         for (int i = 0; i < a.D; ++i) rows_ok = rows_ok && ok(a.st.h[i], a.st.h_ld[i]);
+        // the ReLU-mask records (32 bytes per point, byte offsets below 2^32) and the maxima are always written
+        rows_ok = rows_ok && a.st.maxes && a.st.mask_hv && (uint64_t)a.n_points * 32u < ((uint64_t)1 << 32);
+        for (int i = 0; i < a.D; ++i) rows_ok = rows_ok && a.st.mask[i] && (reinterpret_cast<uintptr_t>(a.st.mask[i]) & 15) == 0;
         if (!rows_ok) return hipErrorInvalidValue;
         static bool raised_store[64] = {};
         if (!raised_store[dev]) {
@@ -774,7 +755,8 @@ __global__ __launch_bounds__(256) void layer_gain_kernel(const float* params, co
 // with weights 2^13 below another's used to lose its low halves, and its small outputs theirs; now neither happens.
 // One workgroup walks the layers in order (a layer's column factors are its producer's row factors); a wavefront takes a
 // row at a time, its lanes along the columns (thread = row made every access a 1 KiB stride: 1.1 ms per network).
-__global__ __launch_bounds__(1024) void equalise_rows_kernel(const float* params, const EqualiseRefs r, float* out) {
+__global__ __launch_bounds__(1024) void equalise_rows_kernel(const float* params, const EqualiseRefs r, float* out,
+                                                             int* row_exp_out) {
     __shared__ int expo[kMaxLinears][256];    // e_j of every linear (0 where rows are not scaled)
     __shared__ int row_exp[256];              // binade of a row's norm, -1000: leave the row alone
     constexpr int kExpBins = 320;             // frexp exponents of finite floats lie within -148 .. 128
@@ -845,18 +827,51 @@ __global__ __launch_bounds__(1024) void equalise_rows_kernel(const float* params
             const float* w = params + r.w_off[k] + (size_t)j * n_in;
             float* o = out + r.w_off[k] + (size_t)j * n_in;
             const int e = expo[k][j];
-            for (int c = lane; c < n_in; c += 64) o[c] = __builtin_ldexpf(column_scaled(w, c), e);
+            for (int c = lane; c < n_in; c += 64) {
+                const int ec = (src >= 0 && c >= c0 && c < c1) ? expo[src][c - c0] : 0;
+                o[c] = __builtin_ldexpf(w[c], e - ec);      // one exact scaling (apply_row_exponents_kernel does the same)
+            }
             if (lane == 0) out[r.b_off[k] + j] = __builtin_ldexpf(params[r.b_off[k] + j], e);
         }
+        // the exponents are kept: apply_row_exponents_kernel re-applies them after optimiser steps, and the training step
+        // turns the equalised network's gradients into the plain parameters' with them (train_dw_kernel.hip)
+        for (int j = threadIdx.x; j < 256; j += blockDim.x) row_exp_out[k * 256 + j] = j < n_out ? expo[k][j] : 0;
         __syncthreads();
     }
 }
 
-hipError_t launch_equalise_rows(const float* params, const EqualiseRefs& refs, float* params_eq, hipStream_t s) {
-    if (refs.n <= 0 || refs.n > kMaxLinears) return hipErrorInvalidValue;
-    for (int k = 0; k < refs.n; ++k)
+// The same copy from exponents chosen EARLIER (equalise_rows_kernel's table): any powers of two give the same function, and
+// a few optimiser steps move a row's norm by far less than a binade, so between full equalisations the training step
+// only re-applies the table - element-wise, every row of every layer at once (the full pass walks the layers in order on one
+// workgroup: 0.4 ms per network, a tenth of a training iteration). Grid (row block of 4, linear); a wavefront per row.
+__global__ __launch_bounds__(256) void apply_row_exponents_kernel(const float* params, const EqualiseRefs r,
+                                                                  const int* row_exp, float* out) {
+    const int k = blockIdx.y, lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= r.n || j >= r.out[k]) return;
+    const int n_in = r.in[k], src = r.col_src[k], c0 = r.hid_col0[k], c1 = c0 + r.n_hid[k];
+    const int e = row_exp[k * 256 + j];
+    const float* w = params + r.w_off[k] + (size_t)j * n_in;
+    float* o = out + r.w_off[k] + (size_t)j * n_in;
+    for (int c = lane; c < n_in; c += 64) {
+        const int ec = (src >= 0 && c >= c0 && c < c1) ? row_exp[src * 256 + c - c0] : 0;
+        o[c] = __builtin_ldexpf(w[c], e - ec);      // (|e|, |ec| <= 30: one exact scaling, as the full pass's two)
+    }
+    if (lane == 0) out[r.b_off[k] + j] = __builtin_ldexpf(params[r.b_off[k] + j], e);
+}
+
+hipError_t launch_equalise_rows(const float* params, const EqualiseRefs& refs, float* params_eq, int* row_exp,
+                                bool reuse_exponents, hipStream_t s) {
+    if (refs.n <= 0 || refs.n > kMaxLinears || !row_exp) return hipErrorInvalidValue;
+    int max_out = 1;
+    for (int k = 0; k < refs.n; ++k) {
         if (refs.out[k] > 256) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(equalise_rows_kernel, dim3(1), dim3(1024), 0, s, params, refs, params_eq);
+        max_out = refs.out[k] > max_out ? refs.out[k] : max_out;
+    }
+    if (reuse_exponents)
+        hipLaunchKernelGGL(apply_row_exponents_kernel, dim3((max_out + 3) / 4, refs.n), dim3(256), 0, s, params, refs, row_exp,
+                           params_eq);
+    else
+        hipLaunchKernelGGL(equalise_rows_kernel, dim3(1), dim3(1024), 0, s, params, refs, params_eq, row_exp);
     return hipGetLastError();
 }
 

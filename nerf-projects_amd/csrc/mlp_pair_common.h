@@ -344,4 +344,124 @@ __device__ __forceinline__ void conv_slice2(XT& dst, const ConvTmp& t) {
     dst.lo[P >> 2][P & 3] = lo;
 }
 
+// ---- shared by the forward (mlp_kernel_h2.hip) and backward-data (mlp_bwd_kernel_h2.hip) kernels -------------------
+__device__ __forceinline__ f32x16 mma(const f32x4& a, const u32x4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
+
+// MFMA K (0..5) of a step, small terms first
+template <int K, bool FIRST>
+__device__ __forceinline__ void mma_one(f32x16& acc, const Frag4& f, const XT& x) {
+#ifdef NERF_MMA_SHARED_OPERANDS
+    // neighbours share an operand: (q0,lo0) (q0,hi0) (q1,hi0) | (q3,hi1) (q2,hi1) (q2,lo1)
+    constexpr int A[6] = {0, 0, 1, 3, 2, 2};
+    constexpr bool LO[6] = {true, false, false, false, false, true};
+#else
+    constexpr int A[6] = {1, 0, 0, 3, 2, 2};
+    constexpr bool LO[6] = {false, true, false, false, true, false};
+#endif
+    constexpr int s = K / 3;
+    const u32x4& b = LO[K] ? x.lo[s] : x.hi[s];
+    if constexpr (K == 0 && FIRST) {
+        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc = mma(f.q[A[K]], b, zero);
+    } else {
+        acc = mma(f.q[A[K]], b, acc);
+    }
+}
+
+// max with the partner lane of the other half-wave: v_permlane32_swap on two copies yields (lo, lo) and (hi, hi)
+// - a vector instruction, no trip through the LDS crossbar and no lgkmcnt wait. From inline asm: through
+// __builtin_amdgcn_permlane32_swap(u, u, ...) hipcc folds max(r[0], r[1]) to r[0] (it takes the two results of a swap
+// of equal inputs for equal), which silently made every lane use the LOWER half-wave's value - harmless while both
+// halves of a point have similar maxima, an fp16 overflow (NaN) when one row of the upper half dominates
+// (tests: test_mlp_precisions_vs_fp64, "one row x2^16").
+__device__ __forceinline__ float half_max(float m) {
+    float a = m, b = m;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// ---- LDS reads outside hipcc's LDS-DMA guard ---------------------------------------------------------------
+// hipcc guards every LDS load it can see with s_waitcnt vmcnt(0) while an LDS-DMA write is in flight (it cannot
+// tell the bias block from the ring), which would drain the weight pipeline at every bias read; these reads are
+// issued from inline asm with their own lgkmcnt wait (LDS returns in order, and the waits hipcc computes for its
+// own reads can only become stricter by the extra entries).
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+}
+struct Tile16 {
+    f32x4 q[4];
+};
+__device__ __forceinline__ Tile16 lds_tile_issue(unsigned addr) {
+    Tile16 t;
+    asm volatile(
+        "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+        "ds_read_b128 %3, %4 offset:48"
+        : "=&v"(t.q[0]), "=&v"(t.q[1]), "=&v"(t.q[2]), "=&v"(t.q[3])
+        : "v"(addr)
+        : "memory");
+    return t;
+}
+__device__ __forceinline__ void lds_tile_wait(Tile16& t) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t.q[0]), "+v"(t.q[1]), "+v"(t.q[2]), "+v"(t.q[3])::"memory");
+}
+
+// a pointer the compiler cannot prove wave-uniform (picked by a loop variable out of the launch record) as one that is:
+// the "s" operands of the stores below must be scalar registers
+template <class P>
+__device__ __forceinline__ P* wave_uniform(P* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (P*)(((unsigned long long)hi << 32) | lo);
+}
+
+// Running maxima for the weight-gradient kernel's scales (MlpBwdLaunch::maxes: float bits, non-negative, so the integer
+// maximum is the float maximum): the wave's maximum by six DPP folds, and an atomic only when the slot does not hold as
+// much already - a thousand waves otherwise queue on one address per layer. The slot is read with a SCALAR load (glc: past
+// the scalar cache) from inline asm: left to hipcc the read became a vector load inside the lane-0 branch, whose
+// s_waitcnt vmcnt(0) drained the LDS-DMA weight ring once per layer.
+__device__ __forceinline__ void enter_max(unsigned* slot_uniform, float m_point, int lane) {
+    unsigned known;
+    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(known) : "s"(slot_uniform) : "memory");
+    const unsigned top = __float_as_uint(wave_max(m_point));
+    if (top > known && top < 0x7f800000u) {
+        if (lane == 0) atomicMax(slot_uniform, top);
+    }
+}
+
+// ---- what the training kernels keep ----------------------------------------------------------------------------
+// 16 bytes of a row-major [points, channels] buffer in ONE instruction: wave-uniform base, one 32-bit byte offset per
+// lane, the rest an immediate (the launchers bound the buffers). (s_nop 1: a store of more than 8 bytes reads its data
+// registers late - two wait states before a vector instruction may overwrite them on gfx950; hipcc's hazard recogniser
+// does not look inside inline asm.)
+template <int IMM>
+__device__ __forceinline__ void keep_quad(float* base, unsigned off, const f32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base), "n"(IMM) : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ void keep_word(unsigned* base, unsigned off, unsigned v) {
+    asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(off), "v"(v), "s"(base), "n"(IMM) : "memory");
+}
+
+// ReLU masks, one bit per unit (MlpStore::mask). The forward kernel's conversion hooks meet a tile's values pair by pair;
+// `hi` is the pair's packed fp16 high halves (non-negative behind a ReLU), so "unit active" is "half non-zero": a packed
+// 16-bit minimum with 1 turns both into flags, and the word collects them by shifting: after the 16 pairs of two tiles,
+// value 2s of tile T sits at bit 15 - 8 (T & 1) - s and value 2s + 1 at bit 31 - 8 (T & 1) - s. (A unit whose value is
+// below 2^-25 of its point's scale rounds to a zero half and counts as inactive: its pre-activation is zero to 2^-35 of
+// the layer's range, where the reference's own sign is rounding noise.)
+__device__ __forceinline__ unsigned mask_push(unsigned field, unsigned hi) {
+    unsigned t;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(hi), "s"(0x00010001u));
+    return (field << 1) | t;
+}
+// all ones where the bit is set: value 2s (ODD = 0) / 2s + 1 (ODD = 1) of tile T, from the word of tiles 2 (T / 2), + 1
+template <int T, int S, int ODD>
+__device__ __forceinline__ unsigned mask_of(unsigned word) {
+    constexpr int bit = (ODD ? 31 : 15) - 8 * (T & 1) - S;
+    return (unsigned)__builtin_amdgcn_sbfe(word, bit, 1);
+}
+
 }  // namespace nerf

@@ -60,15 +60,20 @@ struct TrainState {
     int* d_stream_table = nullptr;   // fused-stream element -> index into params (or -1)
     int* d_bias_table = nullptr;
     int* d_bwd_table = nullptr;      // backward-stream element -> index into params (or -1)
-    float* d_stream_bwd = nullptr;   // transposed-weight stream of the fused backward-data kernel
+    // transposed-weight stream of the fused backward-data kernels, cut from the plain parameters or - when the pass runs in
+    // the equalised network's units (TrainUnits) - from PackedNet::d_params_eq
+    float* d_stream_bwd = nullptr;
     int n_chunks_bwd = 0;
+    bool bwd_dirty = true;           // the master parameters changed since d_stream_bwd (and its fp16-pair twin) were made
+    bool bwd_is_eq = false;          // what d_stream_bwd currently holds
+    // fp16-pair twin of d_stream_bwd (mlp_bwd_kernel_h2.hip): one scale group per transposed matrix, the gains bound a
+    // layer's input gradient from its output gradient: [largest row sum of |W^T|, largest |alpha weight| (layer 1 only)]
+    uint32_t* d_stream_bwd_h2 = nullptr;
+    float* d_descale_bwd = nullptr;
+    float* d_gain_bwd = nullptr;
+    int* d_chunk_layer_bwd = nullptr;
+    float* d_chunk_max_bwd = nullptr;
     bool grads_valid = false;
-    // fp16-pair stream of the PLAIN parameters (no row equalisation: the training forward pass keeps its activations for
-    // the backward pass, so they have to be the network's own), its layer scales and output bounds; made on demand
-    uint32_t* d_stream_h2 = nullptr;
-    float* d_descale = nullptr;
-    float* d_gain = nullptr;
-    bool h2_dirty = true;
 };
 
 struct PackedNet {
@@ -96,6 +101,12 @@ struct PackedNet {
     float* d_stream_eq = nullptr;   // fp32 stream of the equalised parameters (input of the fp16-pair conversion)
     float* d_bias_h2 = nullptr;     // bias block of the equalised parameters
     bool h2_dirty = false;          // the master parameters changed (optimiser step): refresh before the next fp16-pair launch
+    bool f32_dirty = false;         // likewise d_stream / d_bias (the fp32 kernels' inputs)
+    // e_j of every hidden unit ([kMaxLinears][256], 0 where rows are not scaled), written by the full equalisation. Between
+    // full passes (every kEqualiseEvery optimiser steps) the table is re-applied element-wise: any powers of two give the
+    // same function, and a few Adam steps move a row's norm by far less than a binade.
+    int* d_row_exp = nullptr;
+    int eq_age = 0;                 // optimiser steps since the exponents were chosen
     int n_chunks = 0;
     int n_bias_tiles = 0;
     uint32_t skip_in_mask = 0;   // bit i: trunk layer i reads [input_pts, h]
@@ -113,6 +124,15 @@ struct MlpStore {
     int feat_ld;
     float* hv;               // views_linears[0] output (post ReLU), 128 wide
     int hv_ld;
+    // fp16-pair kernels only (the forward pass writes, the backward pass reads; nullptr = not wanted):
+    // ReLU masks, one bit per unit - per point and half-wave h a 16-byte record [4 words] at ((point * 2 + h) * 4): word w
+    // covers the tiles 2w, 2w + 1 of that half-wave's 128 features; value 2s of tile T is bit 15 - 8 (T & 1) - s, value
+    // 2s + 1 bit 31 - 8 (T & 1) - s (the order the conversion hooks meet them in). mask_hv: the view layer's, words 0, 1.
+    unsigned* mask[kMaxDepth];
+    unsigned* mask_hv;
+    // [kBwdMaxSlots] float bits of running maxima (see MlpBwdLaunch::maxes): the forward pass enters the kept activations'
+    // (kBwdMaxKept + i) and the feature vector's (kBwdMaxFeatValue)
+    unsigned* maxes;
 };
 
 struct MlpLaunch {
@@ -151,6 +171,10 @@ struct MlpLaunch {
 // Fused backward-data pass (nerf_mlp_bwd_kernel): from d raw to the gradient at every pre-activation, one launch.
 struct MlpBwdLaunch {
     const float* stream;     // pack_backward_stream
+    const uint32_t* stream_h2;   // its fp16-pair twin, scales and gains (mlp_bwd_kernel_h2.hip only)
+    const float* descale;
+    const float* gain;
+    unsigned* loose;
     int n_chunks;
     const float* bias;       // the forward bias block (carries the rgb / alpha rows per accumulator register)
     int n_bias_tiles;
@@ -166,9 +190,7 @@ struct MlpBwdLaunch {
     unsigned* maxes;
 };
 constexpr int kBwdMaxFeat = kMaxDepth, kBwdMaxViews = kMaxDepth + 1, kBwdMaxKept = 16, kBwdMaxFeatValue = 30, kBwdMaxSlots = 32;
-// kBwdMaxViews: d(view pre-activation); kBwdMaxFeatValue: a BOUND of |feature| (the backward kernel does not read the feature
-// vector): largest row sum of |W_feature| x largest kept h_{D-1} + largest |b| (launch_feature_bound, from the gain table)
-hipError_t launch_feature_bound(const float* gain_feature, unsigned* maxes, int D, hipStream_t s);
+// kBwdMaxViews: d(view pre-activation); kBwdMaxFeatValue: the largest |feature| (entered by the fp16-pair forward pass)
 
 // host-side packer (pack_weights.cpp)
 int pack_weights(const nerf_arch& arch, const float* const* tensors, int n_tensors,
@@ -186,6 +208,17 @@ std::vector<int> chunk_layers(const nerf_arch& arch, uint32_t skip_in_mask);
 hipError_t launch_mlp(const MlpLaunch& a, int mode, hipStream_t s);
 hipError_t launch_mlp_h2(const MlpLaunch& a, int mode, hipStream_t s);
 hipError_t launch_mlp_bwd(const MlpBwdLaunch& b, hipStream_t s);
+hipError_t launch_mlp_bwd_h2(const MlpBwdLaunch& b, hipStream_t s);
+// the transposed matrices of the backward chain, in stream order (0: W_views[:, :W]^T, 1: W_feature^T, b >= 2: trunk layer
+// D - b + 1's hidden columns): gain[2b] = largest row sum of |W^T|, gain[2b + 1] = largest |alpha weight| for b = 1, else 0
+struct BwdGainRefs {
+    int n;
+    unsigned w_off[kMaxDepth + 2];
+    int ld[kMaxDepth + 2], rows[kMaxDepth + 2], col0[kMaxDepth + 2];
+    unsigned alpha_off;
+};
+BwdGainRefs bwd_gain_refs(const nerf_arch& arch, const std::vector<LinearDesc>& linears, uint32_t skip_in_mask);
+hipError_t launch_layer_gains_bwd(const float* params, const BwdGainRefs& refs, float* gain, hipStream_t s);
 // the Linear whose outputs are re-quantised after layer l (trunk 0..D-1, then feature_linear), for launch_layer_gains
 struct GainRefs {
     int n;
@@ -205,10 +238,17 @@ struct EqualiseRefs {
     unsigned w_off[kMaxLinears], b_off[kMaxLinears];
     int scale_rows[kMaxLinears], col_src[kMaxLinears], hid_col0[kMaxLinears], n_hid[kMaxLinears];
 };
-hipError_t launch_equalise_rows(const float* params, const EqualiseRefs& refs, float* params_eq, hipStream_t s);
+// row_exp [kMaxLinears][256]: e_j of every linear (0 where rows are not scaled), written by the full pass and read back when
+// `reuse_exponents` (the element-wise re-application between full passes)
+hipError_t launch_equalise_rows(const float* params, const EqualiseRefs& refs, float* params_eq, int* row_exp,
+                                bool reuse_exponents, hipStream_t s);
+EqualiseRefs equalise_refs(const nerf_arch& arch, const std::vector<LinearDesc>& linears);
 struct PackedNet;
+constexpr int kEqualiseEvery = 32;
 // everything the fp16-pair kernel reads, rebuilt from the master parameters (api.cpp; at load and, lazily, after training steps)
 int refresh_h2(PackedNet& net, hipStream_t s);
+// the fp32 kernels' stream and bias block, likewise
+int refresh_f32(PackedNet& net, hipStream_t s);
 hipError_t launch_convert_stream_h2(const float* stream, const int* chunk_layer, int n_chunks, float* chunk_max,
                                     uint32_t* out, float* descale, hipStream_t s);
 hipError_t launch_embed(const float* x, int64_t n, int multires, float* out, hipStream_t s);
@@ -238,6 +278,15 @@ struct GemmRows {      // C[M,N] = A[M,K] B[K,N]  (+bias) (ReLU) (C *= mask > 0)
     const float* mask; int ldm;
     int accumulate;
 };
+struct GradExps {      // see GradJob
+    const int* row;
+    const int* col;
+    int col_lo, col_hi;
+    __host__ __device__ int of(int m, int n) const {
+        return (row ? row[m] : 0) - ((col && n >= col_lo && n < col_hi) ? col[n] : 0);
+    }
+    __host__ __device__ int of_row(int m) const { return row ? row[m] : 0; }
+};
 struct GemmTN {        // part[slice][Mo, No] = sum_p A[p,Mo]^T B[p,No];  dbp[slice][Mo] = sum_p A[p,Mo]
     const float* A; int lda;
     const float* B; int ldb;
@@ -246,6 +295,7 @@ struct GemmTN {        // part[slice][Mo, No] = sum_p A[p,Mo]^T B[p,No];  dbp[sl
     float* part;
     float* dbp;
     int narrow_first;   // the columns beyond a multiple of 256 come first (cat[gamma(x), h]) rather than last
+    GradExps ex;        // see GradJob
 };
 hipError_t launch_gemm_rows(const GemmRows& g, hipStream_t s);
 hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, float* db, int accumulate, hipStream_t s);
@@ -266,6 +316,12 @@ struct GradJob {
     float* dbp;                   // [n_slices][Mo]
     const unsigned* a_max;        // fp16-pair kernel only: float bits of the largest |dY| and |X| (MlpBwdLaunch::maxes)
     const unsigned* b_max;
+    // A pass that ran on the row-equalised network (PackedNet::d_params_eq: W'[m][n] = 2^(e_m - e_n) W[m][n]) hands over
+    // dY and X in that network's units; by the chain rule dL/dW[m][n] = 2^(e_m - e_n) dL/dW'[m][n] and dL/db[m] =
+    // 2^e_m dL/db'[m] - exact powers of two, applied where the slices are added up. row_exp[m], col_exp[n] (n the column
+    // index inside the Linear's input, scaled only inside [col_lo, col_hi): the hidden part of a concatenated input);
+    // nullptr = 0.
+    GradExps ex;
 };
 constexpr int kMaxGradJobs = 12;
 // points per slice are a multiple of this: whole 32-point tiles for the staged kernel, whole groups of k-steps (two points each,

@@ -44,6 +44,13 @@ struct Linear {
 // group g of a chunk: 64 lanes x 4 consecutive k-steps: lane = (row lane & 31, half h = lane >> 5), group t4 of a unit
 // holds k-steps 4 t4 .. 4 t4 + 3 -> col(t, h).
 
+// a row vector as a one-column matrix: at(r, 0) = w[r] (alpha_linear in the backward pass: d h[r] += w_alpha[r] * d sigma)
+struct ColumnOf {
+    const float* w;
+    int rows;
+    float at(int r, int c) const { return (r < rows && c == 0) ? w[r] : 0.0f; }
+};
+
 // the transpose of the hidden part of a Linear, as the backward-data pass contracts it: d in[r] = sum_c W[c][col0 + r] * d out[c]
 struct LinearT {
     const float* w;   // the Linear's [out, ld] row-major weight
@@ -111,6 +118,9 @@ std::vector<int> chunk_layers(const nerf_arch& a, uint32_t mask) {
 // the same fragment format as the forward stream, every chunk one k-tile against 8 output tiles, for the chain
 //   d feature = W_views[:, :W]^T d(view pre-activation)     4 chunks  (k = the W/2 view units)
 //   d h_{D-1} = W_feature^T d feature                        8 chunks
+//             + w_alpha d sigma                              1 chunk: the alpha row as the column k = 0 of a k-tile, for the
+//                                                            fp16-pair kernel (d sigma rides as one more operand value);
+//                                                            the fp32 kernel adds the rank-1 term itself and passes over it
 //   d h_{i-1} = W_i[:, hidden columns]^T d z_i, i = D-1..1   8 chunks each
 // `tensors` in state_dict order as for pack_weights; validated there.
 int pack_backward_stream(const nerf_arch& a, const float* const* tensors, uint32_t mask, float** stream_out,
@@ -126,6 +136,7 @@ int pack_backward_stream(const nerf_arch& a, const float* const* tensors, uint32
     const float* const* head = tensors + 2 * a.D + 2;
     layer(LinearT{tensors[2 * a.D], a.W, a.W / 2, a.W + a.input_ch_views, 0}, 4);
     layer(LinearT{head[0], a.W, a.W, a.W, 0}, 8);
+    chunk_ktile(st, ColumnOf{head[2], a.W}, 8, [](int t, int h) { return hid_col(0, t, h); });
     for (int i = a.D - 1; i >= 1; --i) {
         const bool pe_in = (mask >> i) & 1;
         layer(LinearT{tensors[2 * i], a.W, a.W, pe_in ? a.W + a.input_ch : a.W, pe_in ? a.input_ch : 0}, 8);

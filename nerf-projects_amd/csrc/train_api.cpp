@@ -36,19 +36,66 @@ int ensure_train_state(nerf_ctx* c, PackedNet& net) {
     return NERF_OK;
 }
 
-// W^T copies for the forward GEMMs and the fused inference stream, from the master parameters
 bool gemm_forward_requested();
 
-int refresh_derived(PackedNet& net, hipStream_t s) {
+// The master parameters changed (first training call on a slot, optimiser step): everything derived from them is stale
+// and is rebuilt by whoever needs it next - the fp32 kernels' stream (refresh_f32), the fp16-pair kernel's equalised
+// stream (refresh_h2), the backward-data streams (refresh_bwd). Only the layer-by-layer forward GEMMs' W^T copies are
+// made here.
+int mark_params_changed(PackedNet& net, hipStream_t s, bool stepped) {
     if (gemm_forward_requested())      // W^T is the B operand of the layer-by-layer forward GEMMs only
         for (const LinearDesc& d : net.linears)
             HIP_TRY(launch_transpose(net.d_params + d.w_off, d.out, d.in, net.train.d_wt + d.w_off, s));
-    HIP_TRY(launch_gather(net.d_params, net.train.d_stream_table, (int64_t)net.stream_table.size(), net.d_stream, s));
-    HIP_TRY(launch_gather(net.d_params, net.train.d_bias_table, (int64_t)net.bias_table.size(), net.d_bias, s));
-    net.h2_dirty = true;      // the fp16-pair kernel's stream, bias block and gains follow at its next launch (refresh_h2)
-    net.train.h2_dirty = true;    // and so does the training forward pass's fp16-pair stream (forward_pass_fused)
-    if (net.train.d_stream_bwd)
-        HIP_TRY(launch_gather(net.d_params, net.train.d_bwd_table, (int64_t)net.bwd_table.size(), net.train.d_stream_bwd, s));
+    if (stepped) {
+        net.f32_dirty = true;
+        net.h2_dirty = true;
+        ++net.eq_age;                  // refresh_h2 chooses new exponents every kEqualiseEvery steps
+    }
+    net.train.bwd_dirty = true;
+    return NERF_OK;
+}
+
+// scale group of every chunk of the backward stream (pack_backward_stream): one per transposed matrix
+std::vector<int> bwd_chunk_layers(const nerf_arch& a) {
+    std::vector<int> ids(4, 0);
+    ids.insert(ids.end(), 8, 1);
+    ids.insert(ids.end(), 1, 1);       // the alpha column shares feature_linear's scale
+    for (int b = 2; b <= a.D; ++b) ids.insert(ids.end(), 8, b);
+    return ids;
+}
+
+// The transposed-weight stream of the fused backward-data kernels, from the parameters whose units the pass runs in
+// (`eq`: the row-equalised copy the fp16-pair forward pass evaluated), and - `pair` - its fp16-pair twin with the gains
+// that bound a layer's input gradient from its output gradient.
+int refresh_bwd(PackedNet& net, bool eq, bool pair, hipStream_t s) {
+    TrainState& t = net.train;
+    if (!t.d_stream_bwd) return NERF_OK;
+    const bool have_pair = t.d_stream_bwd_h2 != nullptr;
+    if (!t.bwd_dirty && t.bwd_is_eq == eq && (!pair || have_pair)) return NERF_OK;
+    HIP_TRY(launch_gather(eq ? net.d_params_eq : net.d_params, t.d_bwd_table, (int64_t)net.bwd_table.size(), t.d_stream_bwd, s));
+    t.bwd_is_eq = eq;
+    if (pair) {
+        const int nb = t.n_chunks_bwd;
+        if (!have_pair) {
+            const std::vector<int> ids = bwd_chunk_layers(net.arch);
+            if ((int)ids.size() != nb) {
+                set_error("internal: %zu scale groups for %d backward chunks", ids.size(), nb);
+                return NERF_E_INVALID;
+            }
+            HIP_TRY(hipMalloc((void**)&t.d_stream_bwd_h2, (size_t)(nb + kStreamTailChunks) * kChunkBytes));
+            HIP_TRY(hipMalloc((void**)&t.d_descale_bwd, (kMaxDepth + 3) * sizeof(float)));
+            HIP_TRY(hipMalloc((void**)&t.d_gain_bwd, 2 * (kMaxDepth + 2) * sizeof(float)));
+            HIP_TRY(hipMalloc((void**)&t.d_chunk_layer_bwd, (size_t)nb * sizeof(int)));
+            HIP_TRY(hipMalloc((void**)&t.d_chunk_max_bwd, (size_t)nb * sizeof(float)));
+            HIP_TRY(hipMemcpyAsync(t.d_chunk_layer_bwd, ids.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));      // (`ids` is a host temporary; once per slot)
+        }
+        HIP_TRY(launch_convert_stream_h2(t.d_stream_bwd, t.d_chunk_layer_bwd, nb, t.d_chunk_max_bwd, t.d_stream_bwd_h2,
+                                         t.d_descale_bwd, s));
+        HIP_TRY(launch_layer_gains_bwd(eq ? net.d_params_eq : net.d_params, bwd_gain_refs(net.arch, net.linears, net.skip_in_mask),
+                                       t.d_gain_bwd, s));
+    }
+    t.bwd_dirty = false;
     return NERF_OK;
 }
 
@@ -67,6 +114,10 @@ struct Pass {              // one network evaluated at P = N*S points with every
     float *g_a = nullptr, *g_b = nullptr, *g_hv = nullptr;   // gradient scratch
     std::vector<float*> dz;      // fused backward: d(pre-activation) of trunk layer i, [P, W]
     bool fused_backward = false;
+    bool eq = false;             // the pass runs in the units of the row-equalised network (fp16-pair forward): see GradJob
+    bool pair_backward = false;  // backward-data on the fp16 pipe (mlp_bwd_kernel_h2.hip); needs `eq`
+    unsigned* mask[kMaxDepth] = {};   // ReLU masks of the trunk layers, one bit per unit (MlpStore::mask), and the view layer's
+    unsigned* mask_hv = nullptr;
     int vcat_ld = 0, C = 4;
 };
 
@@ -79,6 +130,7 @@ size_t pass_floats(const PackedNet& net, int64_t P) {
     f += (size_t)P * 8 * 2;                     // raw, d_raw (<= 8 channels budgeted... out_ch <= 32 handled below)
     f += (size_t)P * 2 * (net.out_ch > 8 ? net.out_ch : 0);
     f += (size_t)P * a.W * 2 + (size_t)P * (a.W / 2);
+    f += (size_t)(a.D + 1) * ((size_t)P * 8 + 64);    // Pass::mask, mask_hv
     return f + 64 * 32;
 }
 
@@ -126,9 +178,13 @@ void carve_pass(Arena& ar, Pass& ps) {
     ps.g_b = ar.take((size_t)P * a.W);
     ps.g_hv = ar.take((size_t)P * (a.W / 2));
     ps.dz.assign(a.D, nullptr);
-    if (ps.fused_backward) {
+    if (ps.fused_backward)
         for (int i = 0; i < a.D; ++i) ps.dz[i] = ar.take((size_t)P * a.W);     // d(pre-activation) of every trunk layer
-        ps.maxes = (unsigned*)ar.take(kBwdMaxSlots);
+    ps.maxes = (unsigned*)ar.take(kBwdMaxSlots);
+    if (ps.eq) {      // (the fp16-pair forward kernel always writes them)
+        // ReLU masks, one bit per unit: [P][2 half-waves][4 words] per trunk layer, the view layer's in the same record size
+        for (int i = 0; i < a.D; ++i) ps.mask[i] = (unsigned*)ar.take((size_t)P * 8);
+        ps.mask_hv = (unsigned*)ar.take((size_t)P * 8);
     }
 }
 
@@ -154,6 +210,16 @@ bool pair_forward_allowed() {
 bool pair_dw_allowed() {
     static const bool on = [] {
         const char* e = getenv("NERF_TRAIN_DW");
+        return !(e && (e[0] == 'f' || e[0] == 'F') && e[1] == '3');
+    }();
+    return on;
+}
+
+// Backward-data follows too (mlp_bwd_kernel_h2.hip) when the forward pass ran on the fp16-pair kernel; NERF_TRAIN_BWD=f32
+// keeps the fp32 kernel (on the same - equalised - transposed weights).
+bool pair_bwd_allowed() {
+    static const bool on = [] {
+        const char* e = getenv("NERF_TRAIN_BWD");
         return !(e && (e[0] == 'f' || e[0] == 'F') && e[1] == '3');
     }();
     return on;
@@ -218,28 +284,28 @@ int forward_pass_fused(Pass& ps, const float* rays, int ray_ld, const float* z, 
         m.st.hv = ps.hv;
         m.st.hv_ld = a.W / 2;
     }
-    if (ps.precision == NERF_PRECISION_F16X2 && pair_forward_allowed() && a.use_viewdirs &&
-        (uint64_t)ps.P * (uint64_t)(a.W + a.input_ch + 4) * 4u < ((uint64_t)1 << 32)) {
-        PackedNet& w = const_cast<PackedNet&>(net);      // (a cache of the parameters, like PackedNet::d_stream_h2)
-        TrainState& t = w.train;
-        if (!t.d_stream_h2) {
-            HIP_TRY(hipMalloc((void**)&t.d_stream_h2, (size_t)(net.n_chunks + kStreamTailChunks) * kChunkBytes));
-            HIP_TRY(hipMalloc((void**)&t.d_descale, (kMaxDepth + 3) * sizeof(float)));
-            HIP_TRY(hipMalloc((void**)&t.d_gain, 2 * (kMaxDepth + 2) * sizeof(float)));
-            t.h2_dirty = true;
+    PackedNet& w = const_cast<PackedNet&>(net);      // (the lazily refreshed streams are caches of the parameters)
+    if (ps.eq) {
+        // the fp16-pair kernel on the row-equalised network - the stream the renderer uses: what it keeps (activations, ReLU
+        // masks, maxima) is in that network's units, and so is everything the backward pass derives from it
+        if (net.h2_dirty) {
+            const int rc = refresh_h2(w, s);
+            if (rc != NERF_OK) return rc;
         }
-        if (t.h2_dirty) {
-            HIP_TRY(launch_convert_stream_h2(net.d_stream, net.d_chunk_layer, net.n_chunks, net.d_chunk_max, t.d_stream_h2,
-                                             t.d_descale, s));
-            HIP_TRY(launch_layer_gains(net.d_params, gain_refs(net.arch, net.linears), t.d_gain, s));
-            t.h2_dirty = false;
-        }
-        m.stream_h2 = t.d_stream_h2;
-        m.descale = t.d_descale;
-        m.gain = t.d_gain;
+        m.stream_h2 = net.d_stream_h2;
+        m.descale = net.d_descale;
+        m.gain = net.d_gain;
+        m.bias = net.d_bias_h2;
         m.loose = ps.loose;
+        m.st.maxes = ps.maxes;
+        for (int i = 0; i < a.D; ++i) m.st.mask[i] = ps.mask[i];
+        m.st.mask_hv = ps.mask_hv;
         HIP_TRY(launch_mlp_h2(m, kInputRays, s));
         return NERF_OK;
+    }
+    if (net.f32_dirty) {
+        const int rc = refresh_f32(w, s);
+        if (rc != NERF_OK) return rc;
     }
     HIP_TRY(launch_mlp(m, kInputRays, s));
     return NERF_OK;
@@ -306,16 +372,31 @@ inline int pick_slices(int64_t P, int Mo, int No, int max_slices) {
     return s < 1 ? 1 : s;
 }
 
+// How the gradient of Linear k is brought back from the equalised network's units (GradJob::ex); all zero otherwise
+GradExps grad_exps(const PackedNet& net, int k, bool eq) {
+    GradExps ex{nullptr, nullptr, 0, 0};
+    if (!eq) return ex;
+    const EqualiseRefs r = equalise_refs(net.arch, net.linears);
+    ex.row = net.d_row_exp + 256 * k;                       // zeros where the rows are not scaled (alpha, rgb)
+    if (r.col_src[k] >= 0) {
+        ex.col = net.d_row_exp + 256 * r.col_src[k] - r.hid_col0[k];
+        ex.col_lo = r.hid_col0[k];
+        ex.col_hi = r.hid_col0[k] + r.n_hid[k];
+    }
+    return ex;
+}
+
 // dW (+db) of one Linear: dW = dY^T X, db = dY^T 1
 int grad_linear(const PackedNet& net, const LinearDesc& d, const float* dY, int ldy, const float* X, int ldx, int64_t P,
-                const TnScratch& sc, hipStream_t s) {
+                const TnScratch& sc, hipStream_t s, bool eq = false) {
     const int n_slices = pick_slices(P, d.out, d.in, sc.max_slices);
     int64_t pps = (P + n_slices - 1) / n_slices;
     pps = (pps + kSlicePointQuantum - 1) / kSlicePointQuantum * kSlicePointQuantum;
     // a trunk layer behind a skip reads cat[gamma(x), h] (nerf.py:79-80): its narrow columns come first; the view layer
     // reads cat[feature, gamma(d)] (nerf.py:93): last
     const bool trunk = &d >= &net.linears[0] && &d < &net.linears[0] + net.arch.D;
-    GemmTN g{dY, ldy, X, ldx, P, d.out, d.in, pps, sc.part, sc.dbp, (trunk && d.in > net.arch.W) ? 1 : 0};
+    GemmTN g{dY, ldy, X, ldx, P, d.out, d.in, pps, sc.part, sc.dbp, (trunk && d.in > net.arch.W) ? 1 : 0,
+             grad_exps(net, (int)(&d - &net.linears[0]), eq)};
     HIP_TRY(launch_gemm_tn(g, n_slices, net.train.d_grad + d.w_off, d.in, net.train.d_grad + d.b_off, sc.accumulate, s));
     return NERF_OK;
 }
@@ -339,10 +420,15 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     const LinearDesc &views = net.linears[a.D], &feat = net.linears[a.D + 1], &alpha = net.linears[a.D + 2],
                      &rgb = net.linears[a.D + 3];
     float* d_feat = ps.g_a;      // [P, W]
+    const bool eq = ps.eq;
+    {
+        const int rc = refresh_bwd(const_cast<PackedNet&>(net), eq, ps.pair_backward, s);
+        if (rc != NERF_OK) return rc;
+    }
     MlpBwdLaunch b{};
     b.stream = net.train.d_stream_bwd;
     b.n_chunks = net.train.n_chunks_bwd;
-    b.bias = net.d_bias;
+    b.bias = eq ? net.d_bias_h2 : net.d_bias;      // (the rgb / alpha rows of the network the pass runs on)
     b.n_bias_tiles = net.n_bias_tiles;
     b.D = a.D;
     b.n_points = ps.P;
@@ -360,28 +446,36 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     b.out.hv_ld = views.out;
     b.out.feat = d_feat;
     b.out.feat_ld = a.W;
+    // (ps.maxes was zeroed before the forward pass, which - on the fp16-pair kernel - has entered the kept activations'
+    // maxima and the feature vector's; the backward kernels add the gradients', the fp32 one the kept ones as well)
     const bool pair_dw = ps.precision == NERF_PRECISION_F16X2 && pair_dw_allowed() && ps.maxes != nullptr;
-    if (pair_dw) {
-        HIP_TRY(hipMemsetAsync(ps.maxes, 0, kBwdMaxSlots * sizeof(unsigned), s));
-        b.maxes = ps.maxes;
+    if (pair_dw || ps.pair_backward) b.maxes = ps.maxes;
+    if (ps.pair_backward) {
+        b.stream_h2 = net.train.d_stream_bwd_h2;
+        b.descale = net.train.d_descale_bwd;
+        b.gain = net.train.d_gain_bwd;
+        b.loose = ps.loose;
+        for (int i = 0; i < a.D; ++i) b.fwd.mask[i] = ps.mask[i];
+        b.fwd.mask_hv = ps.mask_hv;
+        HIP_TRY(launch_mlp_bwd_h2(b, s));
+    } else {
+        HIP_TRY(launch_mlp_bwd(b, s));
     }
-    HIP_TRY(launch_mlp_bwd(b, s));
-    // the view layer's job can join the fp16-pair batch when |feature| is bounded: gain table of the plain parameters (made
-    // for the fp16-pair forward pass of this iteration) x the largest kept h_{D-1}
-    const float* gain_feat = (pair_dw && net.train.d_gain && !net.train.h2_dirty) ? net.train.d_gain + 2 * a.D : nullptr;
-    if (gain_feat) HIP_TRY(launch_feature_bound(gain_feat, ps.maxes, a.D, s));
+    // the view layer's job can join the fp16-pair batch when the feature vector's size is known: the fp16-pair forward pass
+    // has tracked it (kBwdMaxFeatValue)
+    const bool feat_known = pair_dw && eq;
     const float* hl = ps.h[a.D - 1];
     const int hl_ld = ps.h_ld[a.D - 1];
     int rc;
-    if ((rc = grad_linear(net, rgb, ps.d_raw, ps.C, ps.hv, views.out, ps.P, sc, s))) return rc;
-    if ((rc = grad_linear(net, alpha, ps.d_raw + 3, ps.C, hl, hl_ld, ps.P, sc, s))) return rc;
+    if ((rc = grad_linear(net, rgb, ps.d_raw, ps.C, ps.hv, views.out, ps.P, sc, s, eq))) return rc;
+    if ((rc = grad_linear(net, alpha, ps.d_raw + 3, ps.C, hl, hl_ld, ps.P, sc, s, eq))) return rc;
     const bool batched = gemm_tn_is_direct(a.W) && gemm_tn_is_direct(views.out) && a.input_ch <= 64 &&
                          a.input_ch_views <= 64 && a.D + 1 <= kMaxGradJobs;
     if (!batched) {
-        if ((rc = grad_linear(net, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, ps.P, sc, s))) return rc;
-        if ((rc = grad_linear(net, feat, d_feat, a.W, hl, hl_ld, ps.P, sc, s))) return rc;
+        if ((rc = grad_linear(net, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, ps.P, sc, s, eq))) return rc;
+        if ((rc = grad_linear(net, feat, d_feat, a.W, hl, hl_ld, ps.P, sc, s, eq))) return rc;
         for (int i = a.D - 1; i >= 0; --i)
-            if ((rc = grad_linear(net, net.linears[i], ps.dz[i], a.W, ps.in[i], ps.in_ld[i], ps.P, sc, s))) return rc;
+            if ((rc = grad_linear(net, net.linears[i], ps.dz[i], a.W, ps.in[i], ps.in_ld[i], ps.P, sc, s, eq))) return rc;
         return NERF_OK;
     }
     // Every other weight gradient in two launches (+ their reductions): the 256-column blocks of all layers, then the
@@ -394,12 +488,12 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     auto job = [&](GradBatch& b, const LinearDesc& d, const float* dY, int ldy, const float* X, int ldx, int n0, int n1,
                    bool with_db, const unsigned* a_max = nullptr, const unsigned* b_max = nullptr) {
         b.job[b.n++] = GradJob{dY, ldy, X, ldx, d.out, n0, n1, grad + d.w_off, d.in, with_db ? grad + d.b_off : nullptr,
-                               nullptr, nullptr, a_max, b_max};
+                               nullptr, nullptr, a_max, b_max, grad_exps(net, (int)(&d - &net.linears[0]), eq)};
     };
     GradBatch& hidden = pair_dw ? pairs : wide;
     auto mx = [&](int slot) -> const unsigned* { return pair_dw ? ps.maxes + slot : nullptr; };
     job(hidden, feat, d_feat, a.W, hl, hl_ld, 0, a.W, true, mx(kBwdMaxFeat), mx(kBwdMaxKept + a.D - 1));
-    job(gain_feat ? pairs : wide, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, 0, a.W, true, mx(kBwdMaxViews),
+    job(feat_known ? pairs : wide, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, 0, a.W, true, mx(kBwdMaxViews),
         mx(kBwdMaxFeatValue));                                                        // cat[feature, gamma(d)] (nerf.py:93)
     if (views.in > a.W) job(narrow, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, a.W, views.in, false);
     for (int i = a.D - 1; i >= 0; --i) {
@@ -433,7 +527,8 @@ int backward_pass(Pass& ps, const TnScratch& sc, hipStream_t s) {
     if (ps.fused_backward) return backward_pass_fused(ps, sc, s);
     const PackedNet& net = *ps.net;
     const nerf_arch& a = net.arch;
-    const float* prm = net.d_params;
+    const bool eq = ps.eq;
+    const float* prm = eq ? net.d_params_eq : net.d_params;      // the network whose units the forward pass kept
     const float* hl = ps.h[a.D - 1];
     const int hl_ld = ps.h_ld[a.D - 1];
     float* dh = ps.g_a;     // gradient w.r.t. the (post-ReLU, masked to pre-activation) output of the current layer
@@ -443,25 +538,25 @@ int backward_pass(Pass& ps, const TnScratch& sc, hipStream_t s) {
         const LinearDesc &views = net.linears[a.D], &feat = net.linears[a.D + 1], &alpha = net.linears[a.D + 2],
                          &rgb = net.linears[a.D + 3];
         // rgb_linear
-        if ((rc = grad_linear(net, rgb, ps.d_raw, ps.C, ps.hv, views.out, ps.P, sc, s))) return rc;
+        if ((rc = grad_linear(net, rgb, ps.d_raw, ps.C, ps.hv, views.out, ps.P, sc, s, eq))) return rc;
         GemmRows g1{ps.d_raw, ps.C, prm + rgb.w_off, rgb.in, ps.g_hv, views.out, ps.P, views.out, 3, nullptr, 0,
                     ps.hv, views.out, 0};
         HIP_TRY(launch_gemm_rows(g1, s));                       // d(pre-activation of the view layer)
         // views_linears[0]
-        if ((rc = grad_linear(net, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, ps.P, sc, s))) return rc;
+        if ((rc = grad_linear(net, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, ps.P, sc, s, eq))) return rc;
         GemmRows g2{ps.g_hv, views.out, prm + views.w_off, views.in, dh_next, a.W, ps.P, a.W, views.out, nullptr, 0,
                     nullptr, 0, 0};
         HIP_TRY(launch_gemm_rows(g2, s));                       // d feature (first W input columns; no ReLU on feature)
         // feature_linear and alpha_linear both read the last trunk output
-        if ((rc = grad_linear(net, feat, dh_next, a.W, hl, hl_ld, ps.P, sc, s))) return rc;
-        if ((rc = grad_linear(net, alpha, ps.d_raw + 3, ps.C, hl, hl_ld, ps.P, sc, s))) return rc;
+        if ((rc = grad_linear(net, feat, dh_next, a.W, hl, hl_ld, ps.P, sc, s, eq))) return rc;
+        if ((rc = grad_linear(net, alpha, ps.d_raw + 3, ps.C, hl, hl_ld, ps.P, sc, s, eq))) return rc;
         GemmRows g3{dh_next, a.W, prm + feat.w_off, a.W, dh, a.W, ps.P, a.W, a.W, nullptr, 0, nullptr, 0, 0};
         HIP_TRY(launch_gemm_rows(g3, s));
         GemmRows g4{ps.d_raw + 3, ps.C, prm + alpha.w_off, a.W, dh, a.W, ps.P, a.W, 1, nullptr, 0, hl, hl_ld, 1};
         HIP_TRY(launch_gemm_rows(g4, s));                       // += dsigma * w_alpha, then ReLU mask of the trunk output
     } else {
         const LinearDesc& out = net.linears[a.D + 1];
-        if ((rc = grad_linear(net, out, ps.d_raw, ps.C, hl, hl_ld, ps.P, sc, s))) return rc;
+        if ((rc = grad_linear(net, out, ps.d_raw, ps.C, hl, hl_ld, ps.P, sc, s, eq))) return rc;
         GemmRows g1{ps.d_raw, ps.C, prm + out.w_off, a.W, dh, a.W, ps.P, a.W, out.out, nullptr, 0, hl, hl_ld, 0};
         HIP_TRY(launch_gemm_rows(g1, s));
         // views_linears is never evaluated without viewdirs: its gradient is zero
@@ -471,7 +566,7 @@ int backward_pass(Pass& ps, const TnScratch& sc, hipStream_t s) {
     }
     for (int i = a.D - 1; i >= 0; --i) {
         const LinearDesc& d = net.linears[i];
-        if ((rc = grad_linear(net, d, dh, a.W, ps.in[i], ps.in_ld[i], ps.P, sc, s))) return rc;
+        if ((rc = grad_linear(net, d, dh, a.W, ps.in[i], ps.in_ld[i], ps.P, sc, s, eq))) return rc;
         if (i == 0) break;
         // d h_{i-1} = dh W_i[:, hidden columns] masked by ReLU'(layer i-1)
         const int col0 = ((net.skip_in_mask >> i) & 1) ? a.input_ch : 0;
@@ -483,6 +578,18 @@ int backward_pass(Pass& ps, const TnScratch& sc, hipStream_t s) {
         dh_next = t;
     }
     return NERF_OK;
+}
+
+// Which network's units a pass runs in, and which backward kernel follows (after precision / fused_backward are set): the
+// fp16-pair forward kernel evaluates the row-equalised network, so a pass it opens stays in that network's units to the
+// end - the kept activations, the backward-data pass on the equalised transposed weights, the weight gradients, which
+// are brought back to the plain parameters' by exact powers of two where their slices are added up (GradJob::ex).
+void set_units(Pass& ps) {
+    const nerf_arch& a = ps.net->arch;
+    const bool fused_forward = !gemm_forward_requested() && a.D <= kMaxDepth;
+    ps.eq = ps.precision == NERF_PRECISION_F16X2 && pair_forward_allowed() && fused_forward && a.use_viewdirs &&
+            (uint64_t)ps.P * (uint64_t)(a.W + a.input_ch + 4) * 4u < ((uint64_t)1 << 32);
+    ps.pair_backward = ps.eq && ps.fused_backward && pair_bwd_allowed();
 }
 
 }  // namespace
@@ -551,7 +658,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     for (PackedNet* n : {&nc, &nf}) {
         const bool fresh = !n->train.ready;
         if ((rc = ensure_train_state(c, *n))) return rc;
-        if (fresh && (rc = refresh_derived(*n, s))) return rc;
+        if (fresh && (rc = mark_params_changed(*n, s, false))) return rc;
     }
 
     // workspace: sampling buffers + both passes + split-K partials
@@ -585,6 +692,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     pc.fused_backward = !gemm_backward_requested() && nc.train.d_stream_bwd != nullptr && nc.out_ch == 4;
     pc.precision = precision;
     pc.loose = c->d_loose;
+    set_units(pc);
     carve_pass(ar, pc);
     Pass pf;
     if (Si) {
@@ -595,10 +703,13 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
         pf.fused_backward = !gemm_backward_requested() && nf.train.d_stream_bwd != nullptr && nf.out_ch == 4;
         pf.precision = precision;
         pf.loose = c->d_loose;
+        set_units(pf);
         carve_pass(ar, pf);
     }
 
     // ---- forward (render(..., retraw=True, **render_kwargs_train), nerf.ipynb:1258) ----
+    for (Pass* p : {&pc, &pf})
+        if (p->maxes) HIP_TRY(hipMemsetAsync(p->maxes, 0, kBwdMaxSlots * sizeof(unsigned), s));
     HIP_TRY(launch_stratified(r->rays, r->ray_stride, N, Sc, r->lindisp, r->perturb ? r->t_rand : nullptr, z_c, s));
     if ((rc = forward_pass(pc, r->rays, r->ray_stride, z_c, s))) return rc;
     HIP_TRY(launch_composite(pc.raw, pc.C, z_c, r->rays + 3, r->ray_stride, r->noise0, r->white_bkgd, N, Sc, rgb_c, nullptr,
@@ -643,7 +754,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
         for (PackedNet* n : {&nc, &nf}) {
             HIP_TRY(launch_adam(n->d_params, n->train.d_grad, n->train.d_m, n->train.d_v, (int64_t)n->n_params, r->lr,
                                 r->beta1, r->beta2, r->eps, r->step, s));
-            if ((rc = refresh_derived(*n, s))) return rc;
+            if ((rc = mark_params_changed(*n, s, true))) return rc;
             if (!Si || shared) break;
         }
     }
@@ -718,7 +829,7 @@ int nerf_set_adam_state(nerf_ctx* c, int slot, const float* const* exp_avg, cons
     const bool fresh = !net.train.ready;
     int rc = ensure_train_state(c, net);
     if (rc != NERF_OK) return rc;
-    if (fresh && (rc = refresh_derived(net, nullptr))) return rc;
+    if (fresh && (rc = mark_params_changed(net, nullptr, false))) return rc;
     HIP_TRY(hipDeviceSynchronize());
     for (size_t k = 0; k < net.linears.size(); ++k) {
         const LinearDesc& d = net.linears[k];

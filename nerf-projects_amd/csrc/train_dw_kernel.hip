@@ -312,20 +312,9 @@ void grad_batch_pair_kernel(const GradBatch b) {
     }
 }
 
-__global__ void feature_bound_kernel(const float* gain_feature, unsigned* maxes, int D) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const float h = __uint_as_float(maxes[kBwdMaxKept + D - 1]);
-        const float bound = fmaf(gain_feature[0], h, gain_feature[1]);
-        maxes[kBwdMaxFeatValue] = (bound > 0.0f && bound < __builtin_inff()) ? __float_as_uint(bound) : 0u;
-    }
-}
-hipError_t launch_feature_bound(const float* gain_feature, unsigned* maxes, int D, hipStream_t s) {
-    hipLaunchKernelGGL(feature_bound_kernel, dim3(1), dim3(64), 0, s, gain_feature, maxes, D);
-    return hipGetLastError();
-}
-
 // part[s][m][c] summed over the slices in order (deterministic) into dW[m][n_begin + c]; thread = four consecutive elements
-// of one job (eight 16-byte loads in flight), the bias gradients behind them
+// of one job (eight 16-byte loads in flight), the bias gradients behind them. A job whose operands were in the units of the
+// row-equalised network scales its sums by 2^(row_exp[m] - col_exp[n]) here (GradJob): the plain parameters' gradient.
 __global__ __launch_bounds__(256) void grad_batch_reduce_kernel(const GradBatch b) {
     const GradJob& g = b.job[blockIdx.y];
     const int width = g.n_end - g.n_begin;
@@ -356,14 +345,17 @@ __global__ __launch_bounds__(256) void grad_batch_reduce_kernel(const GradBatch 
         for (int c = 0; c < 4; ++c) {
             const int64_t idx = e0 + c;
             if (idx < n_w) {
-                float* w = g.dW + (idx / width) * g.ldw + g.n_begin + (idx % width);
-                *w = b.accumulate ? *w + sum[c] : sum[c];   // second pass through a shared network: .grad accumulates (nerf.ipynb:1270)
+                const int m = (int)(idx / width), n = g.n_begin + (int)(idx % width);
+                const float v = __builtin_ldexpf(sum[c], g.ex.of(m, n));
+                float* w = g.dW + (int64_t)m * g.ldw + n;
+                *w = b.accumulate ? *w + v : v;   // second pass through a shared network: .grad accumulates (nerf.ipynb:1270)
             }
         }
     } else if (g.db && t - quads < g.Mo) {
         const int m = (int)(t - quads);
         float sacc = 0.0f;
         for (int k = 0; k < b.n_slices; ++k) sacc += g.dbp[(int64_t)k * g.Mo + m];
+        sacc = __builtin_ldexpf(sacc, g.ex.of_row(m));
         g.db[m] = b.accumulate ? g.db[m] + sacc : sacc;
     }
 }

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmTN g) {
 // dW[m][n] = sum_s part[s][m][n] and db[m] = sum_s dbp[s][m], slices added in order (deterministic)
 __global__ void reduce_slices_kernel(const float* __restrict__ part, const float* __restrict__ dbp, int n_slices,
                                      int Mo, int No, float* __restrict__ dW, int ldw, float* __restrict__ db,
-                                     int accumulate) {
+                                     int accumulate, const GradExps ex) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n_w = (int64_t)Mo * No;
     if (idx < n_w) {
@@ -383,12 +383,15 @@ __global__ void reduce_slices_kernel(const float* __restrict__ part, const float
             for (int u = 0; u < 8; ++u) s += v[u];
         }
         for (; k < n_slices; ++k) s += part[(int64_t)k * n_w + idx];
-        float* w = dW + (idx / No) * ldw + (idx % No);
+        const int m = (int)(idx / No), n = (int)(idx % No);
+        s = __builtin_ldexpf(s, ex.of(m, n));      // GradJob: equalised units
+        float* w = dW + (int64_t)m * ldw + n;
         *w = accumulate ? *w + s : s;   // second pass through a shared network: .grad accumulates (nerf.ipynb:1270)
     } else if (idx < n_w + Mo && db && dbp) {
         const int m = (int)(idx - n_w);
         float s = 0.0f;
         for (int k = 0; k < n_slices; ++k) s += dbp[(int64_t)k * Mo + m];
+        s = __builtin_ldexpf(s, ex.of_row(m));
         db[m] = accumulate ? db[m] + s : s;
     }
 }
@@ -398,7 +401,7 @@ __global__ void reduce_slices_kernel(const float* __restrict__ part, const float
 // group order through LDS. With one thread per element walking all 2048 slices the pass took 121 us.
 __global__ __launch_bounds__(256) void reduce_many_slices_kernel(const float* __restrict__ part, const float* __restrict__ dbp,
                                                                  int n_slices, int Mo, int No, float* __restrict__ dW, int ldw,
-                                                                 float* __restrict__ db, int accumulate) {
+                                                                 float* __restrict__ db, int accumulate, const GradExps ex) {
     __shared__ float red[16][16];
     const int64_t n_w = (int64_t)Mo * No, n_all = n_w + Mo;       // weights, then the bias entries (from dbp)
     const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -424,10 +427,13 @@ __global__ __launch_bounds__(256) void reduce_many_slices_kernel(const float* __
 #pragma unroll
         for (int g2 = 1; g2 < 16; ++g2) t += red[g2][e];
         if (idx < n_w) {
-            float* w = dW + (idx / No) * ldw + (idx % No);
+            const int m = (int)(idx / No), n = (int)(idx % No);
+            t = __builtin_ldexpf(t, ex.of(m, n));
+            float* w = dW + (int64_t)m * ldw + n;
             *w = accumulate ? *w + t : t;
         } else if (db && dbp) {
             const int m = (int)(idx - n_w);
+            t = __builtin_ldexpf(t, ex.of_row(m));
             db[m] = accumulate ? db[m] + t : t;
         }
     }
@@ -515,7 +521,8 @@ hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, flo
         b.pts_per_slice = g.pts_per_slice;
         if (wide) {
             b.n = 1;
-            b.job[0] = GradJob{g.A, g.lda, g.B, g.ldb, g.Mo, wide_begin, wide_begin + wide, dW, ldw, db, nullptr, nullptr};
+            b.job[0] = GradJob{g.A, g.lda, g.B, g.ldb, g.Mo, wide_begin, wide_begin + wide, dW, ldw, db, nullptr, nullptr,
+                               nullptr, nullptr, g.ex};
             hipError_t e = launch_grad_batch(b, true, g.part, part_floats, g.dbp, dbp_floats, s);
             if (e != hipSuccess) return e;
         }
@@ -524,7 +531,7 @@ hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, flo
             b.n = 0;
             for (int c = 0; c < rest && b.n < kMaxGradJobs; c += 64, ++b.n)
                 b.job[b.n] = GradJob{g.A, g.lda, g.B, g.ldb, g.Mo, nb + c, nb + (c + 64 < rest ? c + 64 : rest), dW, ldw,
-                                     (!wide && c == 0) ? db : nullptr, nullptr, nullptr};
+                                     (!wide && c == 0) ? db : nullptr, nullptr, nullptr, nullptr, nullptr, g.ex};
             if ((rest + 63) / 64 > kMaxGradJobs) return hipErrorInvalidValue;
             // (the wide job's partials have been reduced by now: stream order)
             return launch_grad_batch(b, false, g.part, part_floats, g.dbp, dbp_floats, s);
@@ -535,7 +542,7 @@ hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, flo
         hipLaunchKernelGGL(gemm_tn_small_kernel, dim3((unsigned)n_slices, (unsigned)((g.No + 255) / 256)), dim3(256), 0, s, g);
         const int64_t n_all = (int64_t)g.Mo * g.No + g.Mo;
         hipLaunchKernelGGL(reduce_many_slices_kernel, dim3((unsigned)((n_all + 15) / 16)), dim3(256), 0, s, g.part, g.dbp,
-                           n_slices, g.Mo, g.No, dW, ldw, db, accumulate);
+                           n_slices, g.Mo, g.No, dW, ldw, db, accumulate, g.ex);
         return hipGetLastError();
     } else {
         static bool raised[64] = {};
@@ -547,7 +554,7 @@ hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, flo
     }
     const int64_t total = (int64_t)g.Mo * g.No + g.Mo;
     hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g.part, g.dbp, n_slices,
-                       g.Mo, g.No, dW, ldw, db, accumulate);
+                       g.Mo, g.No, dW, ldw, db, accumulate, g.ex);
     return hipGetLastError();
 }
 

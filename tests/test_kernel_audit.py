@@ -22,7 +22,15 @@ def _load(path, name):
     return mod
 
 
-@pytest.mark.parametrize("src", ["mlp_kernel_h2.hip"])
+KERNELS = {
+    # the three input modes of the inference kernel and the training forward kernel (rays, STORE)
+    "mlp_kernel_h2.hip": (("kernelILi0ELb0E", "kernelILi1ELb0E", "kernelILi2ELb0E", "kernelILi2ELb1E"), 1000, 400),
+    # the training backward-data kernel on the same machinery
+    "mlp_bwd_kernel_h2.hip": (("nerf_mlp_bwd_h2_kernel",), 600, 300),
+}
+
+
+@pytest.mark.parametrize("src", sorted(KERNELS))
 def test_no_register_touched_before_its_lds_wait(src, tmp_path):
     build = _load(os.path.join(PKG, "build.py"), "nerf_build_for_audit")
     audit = _load(os.path.join(ROOT, "tools", "audit_lds_waits.py"), "audit_lds_waits")
@@ -31,11 +39,14 @@ def test_no_register_touched_before_its_lds_wait(src, tmp_path):
         ["-I", os.path.join(ROOT, "include"), "-I", build.CSRC, "--cuda-device-only", "-S",
          os.path.join(build.CSRC, src), "-o", str(out)]
     subprocess.run(cmd, check=True, cwd=tmp_path)
-    seen = 0
-    # the three input modes of the inference kernel and the training forward kernel (rays, STORE)
-    for inst in ("kernelILi0ELb0E", "kernelILi1ELb0E", "kernelILi2ELb0E", "kernelILi2ELb1E"):
+    names, min_ops, min_waits = KERNELS[src]
+    for inst in names:
         findings, n_ops, n_waits = audit.audit(str(out), inst)
-        assert n_ops > 1000 and n_waits > 400, (inst, n_ops, n_waits)   # the kernel was found and parsed
+        assert n_ops > min_ops and n_waits > min_waits, (inst, n_ops, n_waits)   # the kernel was found and parsed
         assert not findings, (inst, findings[:5])
-        seen += 1
-    assert seen == 4
+    # no scratch: a spilled register is reloaded through the vector-memory counter, which the weight ring's waits own
+    text = open(out).read()
+    for inst in names:
+        body = text[text.index(inst):]
+        body = body[:body.index("s_endpgm")]
+        assert "scratch_" not in body, inst

@@ -173,11 +173,12 @@ def test_render_rays_end_to_end(weights_pair, name, kw):
 def test_render_rays_bench_scale(weights_pair):
     """The 4096 rays of the 800x800 lego frame that bench.py's parity leg samples: the oracle against the reference's
     own fp32 render, anchored on the reference's fp32-vs-fp64 behaviour on the same rays (tests/golden/bench_frame.npz;
-    every 4th ray here to keep the CPU suite short - the GPU test and bench.py use all 4096)."""
+    all 4096 rays, as the GPU test and bench.py use them: the flip counts - 6 for the reference against its own fp64 render -
+    are too small to be compared on a subsample)."""
     g = load_golden("bench_frame")
     net_c, net_f, q = _oracle_nets(weights_pair)
     kw = dict(N_samples=64, N_importance=128, network_fine=net_f, white_bkgd=True)
-    sub = {k: g[k][::4] for k in g.files}
+    sub = {k: g[k] for k in g.files}
     ex = {}
     ret = O.render_rays(sub["rays"], net_c, q, _extras=ex, **kw)
     z_fine = np.sort(np.concatenate([ex["z_coarse"], sub["z_samples"]], -1), -1)       # nerf.ipynb:467
@@ -185,7 +186,7 @@ def test_render_rays_bench_scale(weights_pair):
     for k in ("rgb0", "acc0"):
         assert np.abs(ret[k] - sub[k]).max() <= 5e-6, k
     st = check_resampled(ret, sub, injected=inj, fp64=sub, foreground=sub["acc0"] > 1e-3)
-    assert st["foreground_rays"] > 300 and st["rgb_fg_median"] <= 2e-6
+    assert st["foreground_rays"] > 1200 and st["rgb_fg_median"] <= 2e-6
 
 
 def test_render_rays_variants(weights_pair):

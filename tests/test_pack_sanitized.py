@@ -185,12 +185,18 @@ def repack(D, W, in_ch, in_v, out_ch, viewdirs, skips):
         for c in range(3):
             bias += row_tiles(rgb, c, 4)
         n_out = 4
-        # backward stream: W_views[:, :W]^T (4 k-tiles), W_feature^T, W_i[:, hidden]^T for i = D-1..1, 8 output tiles each
+        # backward stream: W_views[:, :W]^T (4 k-tiles), W_feature^T, the alpha column, W_i[:, hidden]^T for i = D-1..1
         def layer_t(T, n_kt):
             for kt in range(n_kt):
                 bwd.append(chunk_ktile(T, 8, lambda t, h, kt=kt: hidden_col(kt, t, h)))
         layer_t(LinT(views, W, W // 2, 0), 4)
         layer_t(LinT(feature, W, W, 0), 8)
+
+        class AlphaColumn:      # the alpha row as column k = 0 of one more k-tile (d h += w_alpha * d sigma on the matrix pipe)
+            @staticmethod
+            def at(r, c):
+                return alpha.w[0, r] if (r < W and c == 0) else 0.0
+        bwd.append(chunk_ktile(AlphaColumn, 8, lambda t, h: hidden_col(0, t, h)))
         for i in range(D - 1, 0, -1):
             layer_t(LinT(lins[i], W, W, in_ch if (mask >> i) & 1 else 0), 8)
     else:
