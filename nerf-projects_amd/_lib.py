@@ -20,6 +20,7 @@ EXPORTS = (
     "nerf_get_gradients", "nerf_stratified_z", "nerf_resample", "nerf_render_frame", "nerf_set_precision",
     "nerf_get_precision", "nerf_precision_status", "nerf_get_adam_state", "nerf_set_adam_state",
     "nerf_shard_bounds", "nerf_render_shard", "nerf_precision_peek", "nerf_precision_check",
+    "nerf_precision_detail",
 )
 NERF_W_PRECISION, NERF_W_PRECISION_FALLBACK = 1, 2
 NERF_GUARD_OFF, NERF_GUARD_REPORT, NERF_GUARD_FALLBACK = 0, 1, 2
@@ -149,6 +150,8 @@ def load():
     lib.nerf_set_adam_state.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), i32]
     lib.nerf_precision_status.restype = i32
     lib.nerf_precision_status.argtypes = [vp, C.POINTER(i64), i32]
+    lib.nerf_precision_detail.restype = i32
+    lib.nerf_precision_detail.argtypes = [vp, C.POINTER(i64), i32]
     lib.nerf_precision_peek.restype = i32
     lib.nerf_precision_peek.argtypes = [vp, C.POINTER(i64)]
     lib.nerf_precision_check.restype = i32

@@ -160,10 +160,7 @@ int refresh_f32(PackedNet& net, hipStream_t s) {
 }
 
 int refresh_h2(PackedNet& net, hipStream_t s) {
-    // the exponents are chosen afresh at load time and every kEqualiseEvery optimiser steps; in between they are re-applied
-    const bool reuse = net.eq_age > 0 && net.eq_age < kEqualiseEvery;
-    HIP_TRY(launch_equalise_rows(net.d_params, equalise_refs(net.arch, net.linears), net.d_params_eq, net.d_row_exp, reuse, s));
-    if (!reuse) net.eq_age = 0;
+    HIP_TRY(launch_equalise_rows(net.d_params, equalise_refs(net.arch, net.linears), net.d_params_eq, net.d_row_exp, s));
     HIP_TRY(launch_gather(net.d_params_eq, net.train.d_stream_table, (int64_t)net.stream_table.size(), net.d_stream_eq, s));
     HIP_TRY(launch_gather(net.d_params_eq, net.train.d_bias_table, (int64_t)net.bias_table.size(), net.d_bias_h2, s));
     HIP_TRY(launch_convert_stream_h2(net.d_stream_eq, net.d_chunk_layer, net.n_chunks, net.d_chunk_max, net.d_stream_h2,
@@ -290,8 +287,8 @@ int nerf_ctx_create(int device, nerf_ctx** out) {
     c->device = device;
     {
         DeviceGuard g(device);
-        hipError_t e2 = hipMalloc((void**)&c->d_loose, sizeof(unsigned));
-        if (e2 == hipSuccess) e2 = hipMemset(c->d_loose, 0, sizeof(unsigned));
+        hipError_t e2 = hipMalloc((void**)&c->d_loose, kLooseWords * sizeof(unsigned));
+        if (e2 == hipSuccess) e2 = hipMemset(c->d_loose, 0, kLooseWords * sizeof(unsigned));
         if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&c->h_loose, sizeof(unsigned), hipHostMallocDefault);
         if (e2 == hipSuccess) *c->h_loose = 0u;
         if (e2 != hipSuccess) {
@@ -883,11 +880,29 @@ int nerf_precision_status(nerf_ctx* c, int64_t* loose_bound_events, int reset) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(&v, c->d_loose, sizeof(v), hipMemcpyDeviceToHost));
     if (reset) {
-        HIP_TRY(hipMemset(c->d_loose, 0, sizeof(v)));
+        HIP_TRY(hipMemset(c->d_loose, 0, kLooseWords * sizeof(unsigned)));
         if (c->h_loose) *c->h_loose = 0u;
         c->loose_seen = 0u;
     }
     *loose_bound_events = (int64_t)v;
+    return NERF_OK;
+}
+
+int nerf_precision_detail(nerf_ctx* c, int64_t* counts, int reset) {
+    if (!c || !counts) {
+        set_error("nerf_precision_detail: NULL argument");
+        return NERF_E_INVALID;
+    }
+    DeviceGuard g(c->device);
+    unsigned v[kLooseWords] = {};
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(v, c->d_loose, sizeof(v), hipMemcpyDeviceToHost));
+    if (reset) {
+        HIP_TRY(hipMemset(c->d_loose, 0, sizeof(v)));
+        if (c->h_loose) *c->h_loose = 0u;
+        c->loose_seen = 0u;
+    }
+    for (int i = 0; i < kLooseWords; ++i) counts[i] = (int64_t)v[i];
     return NERF_OK;
 }
 

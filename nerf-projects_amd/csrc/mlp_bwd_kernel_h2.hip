@@ -112,6 +112,7 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
     //   [0] d raw of the tile (one tile ahead)   [1] the view layer's mask (one tile ahead)   [2] a trunk layer's mask (requested
     //   when the layer's chunks begin, read when they end)
     __shared__ __attribute__((aligned(16))) char pre_lds[kWavesPerGroup][3][kPreSlotBytes];
+    __shared__ unsigned max_record[kWavesPerGroup][kBwdMaxSlots];      // enter_max: what each wave has entered so far
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
@@ -126,6 +127,7 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
     prefetch_pieces<0, 4>(piece_src(pipe, 2), piece_dst(pipe, 2));   // chunk 0's first-half steps issue the other four
     // rgb_linear's rows: bias-block tiles 8D+22 .. 8D+33 (pack_weights.cpp row_tiles)
     for (int i = threadIdx.x; i < kRgbRowFloats; i += 256) rgb_lds[i] = b.bias[(8 * D + 22) * kBiasTileFloats + i];
+    if (threadIdx.x < kWavesPerGroup * kBwdMaxSlots) (&max_record[0][0])[threadIdx.x] = 0u;
     if ((int)threadIdx.x <= D) {
         const int l = threadIdx.x;
         layer_tab[4 * l] = b.descale[l];
@@ -211,7 +213,7 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
                 }
             }
             m_prev = half_max(m);
-            if (b.maxes) enter_max(wave_uniform(b.maxes + kBwdMaxViews), m_prev, lane);
+            if (b.maxes) enter_max(wave_uniform(b.maxes + kBwdMaxViews), &max_record[wave][kBwdMaxViews], m_prev, lane);
             const int t_v = pick_exponent(m_prev);
             const float sc = pow2f(t_v);
 #pragma unroll
@@ -247,9 +249,16 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
         };
         auto close_pending = [&](int slot) {
             m_prev = half_max(pd.m);
-            const int slack = 10 - pd.t_out - __builtin_amdgcn_frexp_expf(m_prev);
-            if (m_prev > 0.0f && slack >= 12 && pd.t_out > -60 && b.loose) atomicAdd(b.loose, 1u);
-            if (b.maxes && slot >= 0) enter_max(wave_uniform(b.maxes + slot), m_prev, lane);
+            // how far the bound overshot (d sigma shares d feature's scale group: it counts as a member). Counted by size
+            // (nerf_precision_detail); from 2^kLooseBwdGuard on also where the precision guard looks.
+            const float m_grp = slot == kBwdMaxFeat ? fmaxf(m_prev, dsig_abs) : m_prev;
+            const int slack = 10 - pd.t_out - __builtin_amdgcn_frexp_expf(m_grp);
+            if (m_grp > 0.0f && slack >= 12 && pd.t_out > -60 && b.loose) {
+                const int bucket = 1 + (slack >= 24 ? 6 : (slack - 12) >> 1);
+                atomicAdd(b.loose + bucket, 1u);
+                if (slack >= kLooseBwdGuard) atomicAdd(b.loose, 1u);
+            }
+            if (b.maxes && slot >= 0) enter_max(wave_uniform(b.maxes + slot), &max_record[wave][slot], m_prev, lane);
         };
 
         // ---- d feature = W_views[:, :W]^T d(view pre-activation): four k-tiles, nothing pending yet ----

@@ -121,6 +121,7 @@ __device__ __forceinline__ void convert_pair(XT& dst, const f32x16& src, Pending
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(a1));
     dst.hi[P >> 2][P & 3] = hi;
     dst.lo[P >> 2][P & 3] = lo;
+#ifndef NERF_ABLATE_MASKS
     if constexpr (STORE) {
         pd.maskw = mask_push(pd.maskw, hi);
         if constexpr (P == 7 && (T & 1) == 1) {      // tiles 2w, 2w + 1 done: word w of the record
@@ -128,6 +129,7 @@ __device__ __forceinline__ void convert_pair(XT& dst, const f32x16& src, Pending
             pd.maskw = 0u;
         }
     }
+#endif
 }
 
 // a whole tile at once (not hidden: tile 0 at the start of a layer)
@@ -195,6 +197,7 @@ __device__ __forceinline__ void chunk_ktile8(PipeH& p, Frag4& cur, f32x16 (&acc)
             else if constexpr (pt == 13) conv_slice2<s>(hid[C0], t);
             else if constexpr (pt == 14) {
                 if constexpr (s < 7) r = lds_pair_issue<128 * C0 + 8 * (s + 1)>(pd.bias_addr);
+#ifndef NERF_ABLATE_MASKS
                 if constexpr (STORE) {      // the pair's ReLU flags (MlpStore::mask)
                     pd.maskw = mask_push(pd.maskw, hid[C0].hi[s >> 2][s & 3]);
                     if constexpr (s == 7 && (C0 & 1) == 1) {
@@ -202,6 +205,7 @@ __device__ __forceinline__ void chunk_ktile8(PipeH& p, Frag4& cur, f32x16 (&acc)
                         pd.maskw = 0u;
                     }
                 }
+#endif
             }
         }
     });
@@ -330,6 +334,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
     extern __shared__ __attribute__((aligned(16))) char ring_lds[];
     __shared__ __attribute__((aligned(16))) float bias_lds[kBiasLdsBytes / 4];
     __shared__ __attribute__((aligned(16))) float layer_tab[4 * (kMaxDepth + 3)];   // per layer [descale, gain, max|b|, -]
+    __shared__ unsigned max_record[STORE ? kWavesPerGroup : 1][kBwdMaxSlots];      // STORE: enter_max's per-wave records
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
@@ -345,6 +350,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
     }
     prefetch_pieces<0, 4>(piece_src(pipe, 2), piece_dst(pipe, 2));   // chunk 0's first-half steps issue the other four
     for (int i = threadIdx.x; i < a.n_bias_tiles * kBiasTileFloats; i += 256) bias_lds[i] = a.bias[i];
+    if (STORE && threadIdx.x < kWavesPerGroup * kBwdMaxSlots) (&max_record[0][0])[threadIdx.x] = 0u;
     if (threadIdx.x < a.D + 3) {
         const int l = threadIdx.x;
         const bool has_gain = l <= (a.use_viewdirs ? a.D : a.D - 1);
@@ -452,7 +458,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             m_prev = half_max(pd.m);
             if constexpr (STORE) {
                 // the largest kept activation of this layer, for the weight-gradient kernel's scale (MlpStore::maxes)
-                enter_max(wave_uniform(a.st.maxes + slot), m_prev, lane);
+                enter_max(wave_uniform(a.st.maxes + slot), &max_record[wave][slot], m_prev, lane);
             }
             // the scale was chosen for a bound of 2^(10 - t_out); outputs 2^12 and more below it have begun to lose
             // low-half bits (see Pending). Counted, never silent: nerf_precision_status.
@@ -753,10 +759,13 @@ __global__ __launch_bounds__(256) void layer_gain_kernel(const float* params, co
 // function unchanged - exactly, the factors being powers of two - while every row of a layer gets the same norm
 // binade (the layer's median). The fp16-pair kernel scales a LAYER's weights by one factor and a POINT's activations by one factor: a unit
 // with weights 2^13 below another's used to lose its low halves, and its small outputs theirs; now neither happens.
-// One workgroup walks the layers in order (a layer's column factors are its producer's row factors); a wavefront takes a
-// row at a time, its lanes along the columns (thread = row made every access a 1 KiB stride: 1.1 ms per network).
-__global__ __launch_bounds__(1024) void equalise_rows_kernel(const float* params, const EqualiseRefs r, float* out,
-                                                             int* row_exp_out) {
+// Two kernels. row_exponents_kernel chooses the e_j: one workgroup walks the layers in order (a layer's column factors are
+// its producer's row factors); a wavefront takes four rows at a time, its lanes along the columns, all of their loads in
+// flight together. It only READS the parameters (0.6 MB) and writes the table of exponents; apply_row_exponents_kernel then
+// writes the equalised copy element-wise, every row of every layer at once. (One kernel doing both on one workgroup took
+// 0.4 ms per network; the training step equalises both networks after every optimiser step, so that a step stays a
+// function of the parameters alone - a resumed run repeats the original bit for bit.)
+__global__ __launch_bounds__(1024) void row_exponents_kernel(const float* params, const EqualiseRefs r, int* row_exp_out) {
     __shared__ int expo[kMaxLinears][256];    // e_j of every linear (0 where rows are not scaled)
     __shared__ int row_exp[256];              // binade of a row's norm, -1000: leave the row alone
     constexpr int kExpBins = 320;             // frexp exponents of finite floats lie within -148 .. 128
@@ -766,39 +775,48 @@ __global__ __launch_bounds__(1024) void equalise_rows_kernel(const float* params
     for (int idx = 0; idx < r.n; ++idx) {
         const int k = r.order[idx];
         const int n_out = r.out[k], n_in = r.in[k], src = r.col_src[k], c0 = r.hid_col0[k], c1 = c0 + r.n_hid[k];
-        auto column_scaled = [&](const float* w, int c) {
-            const float v = w[c];
-            return (src >= 0 && c >= c0 && c < c1) ? __builtin_ldexpf(v, -expo[src][c - c0]) : v;
-        };
         if (r.scale_rows[k]) {
             // binade of every row's NORM: with inputs of comparable size a unit's output scales with
             // the l2 norm of its row and bias (the largest |w| misjudges a row that copies one input next to rows that
             // sum 256) - rows of zeros with a zero bias and non-finite rows keep factor 1
-            for (int j = wave; j < n_out; j += n_waves) {
-                const float* w = params + r.w_off[k] + (size_t)j * n_in;
-                double m2 = 0.0;                            // (double: |w| up to FLT_MAX squares without overflow)
-                for (int c = lane; c < n_in; c += 64) {
-                    const double v = (double)column_scaled(w, c);
-                    m2 += v * v;
-                }
-                for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
-                {   // the bias counts as a weight on a constant input: a row of zeros with a bias is a unit of size |b|
-                    const double bj = (double)params[r.b_off[k] + j];
-                    m2 += bj * bj;
-                }
-                if (lane == 0) {
-                    int ej = -1000;
-                    if (m2 > 0.0 && m2 < (double)__builtin_inff() * (double)__builtin_inff()) (void)frexp(sqrt(m2), &ej);
-                    row_exp[j] = ej;
+            for (int q = threadIdx.x; q < kExpBins; q += blockDim.x) hist[q] = 0;
+            if (threadIdx.x == 0) n_valid = 0;
+            constexpr int kRows = 4, kCols = 6;        // rows per wave and round; 64 x 6 = 384 columns cover in <= 383
+            for (int j0 = wave * kRows; j0 < n_out; j0 += n_waves * kRows) {
+                float v[kRows][kCols];
+#pragma unroll
+                for (int a = 0; a < kRows; ++a)
+#pragma unroll
+                    for (int t = 0; t < kCols; ++t) {
+                        const int j = j0 + a, c = lane + 64 * t;
+                        v[a][t] = (j < n_out && c < n_in) ? params[r.w_off[k] + (size_t)j * n_in + c] : 0.0f;
+                    }
+#pragma unroll
+                for (int a = 0; a < kRows; ++a) {
+                    const int j = j0 + a;
+                    double m2 = 0.0;                            // (double: |w| up to FLT_MAX squares without overflow)
+#pragma unroll
+                    for (int t = 0; t < kCols; ++t) {
+                        const int c = lane + 64 * t;
+                        const int ec = (src >= 0 && c >= c0 && c < c1) ? expo[src][c - c0] : 0;
+                        const double x = (double)__builtin_ldexpf(v[a][t], -ec);
+                        m2 += x * x;
+                    }
+                    for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
+                    if (lane == 0 && j < n_out) {
+                        // the bias counts as a weight on a constant input: a row of zeros with a bias is a unit of size |b|
+                        const double bj = (double)params[r.b_off[k] + j];
+                        m2 += bj * bj;
+                        int ej = -1000;
+                        if (m2 > 0.0 && m2 < (double)__builtin_inff() * (double)__builtin_inff()) (void)frexp(sqrt(m2), &ej);
+                        row_exp[j] = ej;
+                    }
                 }
             }
             __syncthreads();
             // towards the MEDIAN binade, not the largest: the ordinary units keep their scale - a skip layer concatenates
             // them with gamma(x), whose entries are not scaled, and one huge row must not push 255 others 2^20 above those
-            // (a histogram over the binades a float's norm can have, walked by one thread)
-            for (int q = threadIdx.x; q < kExpBins; q += blockDim.x) hist[q] = 0;
-            if (threadIdx.x == 0) n_valid = 0;
-            __syncthreads();
+            // (a histogram over the binades a float's norm can have)
             for (int j = threadIdx.x; j < n_out; j += blockDim.x)
                 if (row_exp[j] > -1000) {
                     const int q = row_exp[j] + kExpBins / 2;
@@ -806,44 +824,46 @@ __global__ __launch_bounds__(1024) void equalise_rows_kernel(const float* params
                     atomicAdd(&n_valid, 1);
                 }
             __syncthreads();
-            if (threadIdx.x == 0) {
-                int q = 0, seen = 0;
-                for (; q < kExpBins; ++q) {
-                    seen += hist[q];
-                    if (seen > n_valid / 2) break;       // the smallest binade with more than half of the rows at or below it
+            if (wave == 0) {
+                // the smallest binade with more than half of the rows at or below it: lane l owns bins 5 l .. 5 l + 4
+                int own = 0;
+                for (int q = 5 * lane; q < 5 * lane + 5; ++q) own += hist[q];
+                int incl = own;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(incl, o);
+                    if (lane >= o) incl += t;
                 }
-                median_exp = n_valid > 0 ? q - kExpBins / 2 : 0;
+                const int half = n_valid / 2;
+                const unsigned long long over = __ballot(incl > half);
+                if (over != 0ull && lane == __builtin_ctzll(over)) {
+                    int seen = incl - own, q = 5 * lane;
+                    for (; q < 5 * lane + 5; ++q) {
+                        seen += hist[q];
+                        if (seen > half) break;
+                    }
+                    median_exp = q - kExpBins / 2;
+                }
+                if (over == 0ull && lane == 0) median_exp = 0;      // (no valid row)
             }
             __syncthreads();
-            for (int j = threadIdx.x; j < n_out; j += blockDim.x) {
-                int e = row_exp[j] > -1000 ? median_exp - row_exp[j] : 0;
-                expo[k][j] = e > 30 ? 30 : (e < -30 ? -30 : e);   // a unit 2^30 off the median is not brought all the way
+            for (int j = threadIdx.x; j < 256; j += blockDim.x) {
+                int e = (j < n_out && row_exp[j] > -1000) ? median_exp - row_exp[j] : 0;
+                e = e > 30 ? 30 : (e < -30 ? -30 : e);      // a unit 2^30 off the median is not brought all the way
+                expo[k][j] = e;
+                row_exp_out[k * 256 + j] = e;
             }
         } else {
-            for (int j = threadIdx.x; j < n_out; j += blockDim.x) expo[k][j] = 0;
-        }
-        __syncthreads();
-        for (int j = wave; j < n_out; j += n_waves) {
-            const float* w = params + r.w_off[k] + (size_t)j * n_in;
-            float* o = out + r.w_off[k] + (size_t)j * n_in;
-            const int e = expo[k][j];
-            for (int c = lane; c < n_in; c += 64) {
-                const int ec = (src >= 0 && c >= c0 && c < c1) ? expo[src][c - c0] : 0;
-                o[c] = __builtin_ldexpf(w[c], e - ec);      // one exact scaling (apply_row_exponents_kernel does the same)
+            for (int j = threadIdx.x; j < 256; j += blockDim.x) {
+                expo[k][j] = 0;
+                row_exp_out[k * 256 + j] = 0;
             }
-            if (lane == 0) out[r.b_off[k] + j] = __builtin_ldexpf(params[r.b_off[k] + j], e);
         }
-        // the exponents are kept: apply_row_exponents_kernel re-applies them after optimiser steps, and the training step
-        // turns the equalised network's gradients into the plain parameters' with them (train_dw_kernel.hip)
-        for (int j = threadIdx.x; j < 256; j += blockDim.x) row_exp_out[k * 256 + j] = j < n_out ? expo[k][j] : 0;
         __syncthreads();
     }
 }
 
-// The same copy from exponents chosen EARLIER (equalise_rows_kernel's table): any powers of two give the same function, and
-// a few optimiser steps move a row's norm by far less than a binade, so between full equalisations the training step
-// only re-applies the table - element-wise, every row of every layer at once (the full pass walks the layers in order on one
-// workgroup: 0.4 ms per network, a tenth of a training iteration). Grid (row block of 4, linear); a wavefront per row.
+// out[k][j][c] = params[k][j][c] * 2^(e_kj - e_src(k),c) (row_exponents_kernel's table; exact): the copy of the network the
+// fp16-pair kernels evaluate. Grid (row block of 4, linear); a wavefront per row.
 __global__ __launch_bounds__(256) void apply_row_exponents_kernel(const float* params, const EqualiseRefs r,
                                                                   const int* row_exp, float* out) {
     const int k = blockIdx.y, lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -854,24 +874,21 @@ __global__ __launch_bounds__(256) void apply_row_exponents_kernel(const float* p
     float* o = out + r.w_off[k] + (size_t)j * n_in;
     for (int c = lane; c < n_in; c += 64) {
         const int ec = (src >= 0 && c >= c0 && c < c1) ? row_exp[src * 256 + c - c0] : 0;
-        o[c] = __builtin_ldexpf(w[c], e - ec);      // (|e|, |ec| <= 30: one exact scaling, as the full pass's two)
+        o[c] = __builtin_ldexpf(w[c], e - ec);      // (|e|, |ec| <= 30: one exact scaling)
     }
     if (lane == 0) out[r.b_off[k] + j] = __builtin_ldexpf(params[r.b_off[k] + j], e);
 }
 
-hipError_t launch_equalise_rows(const float* params, const EqualiseRefs& refs, float* params_eq, int* row_exp,
-                                bool reuse_exponents, hipStream_t s) {
+hipError_t launch_equalise_rows(const float* params, const EqualiseRefs& refs, float* params_eq, int* row_exp, hipStream_t s) {
     if (refs.n <= 0 || refs.n > kMaxLinears || !row_exp) return hipErrorInvalidValue;
     int max_out = 1;
     for (int k = 0; k < refs.n; ++k) {
-        if (refs.out[k] > 256) return hipErrorInvalidValue;
+        if (refs.out[k] > 256 || refs.in[k] > 383) return hipErrorInvalidValue;
         max_out = refs.out[k] > max_out ? refs.out[k] : max_out;
     }
-    if (reuse_exponents)
-        hipLaunchKernelGGL(apply_row_exponents_kernel, dim3((max_out + 3) / 4, refs.n), dim3(256), 0, s, params, refs, row_exp,
-                           params_eq);
-    else
-        hipLaunchKernelGGL(equalise_rows_kernel, dim3(1), dim3(1024), 0, s, params, refs, params_eq, row_exp);
+    hipLaunchKernelGGL(row_exponents_kernel, dim3(1), dim3(1024), 0, s, params, refs, row_exp);
+    hipLaunchKernelGGL(apply_row_exponents_kernel, dim3((max_out + 3) / 4, refs.n), dim3(256), 0, s, params, refs, row_exp,
+                       params_eq);
     return hipGetLastError();
 }
 

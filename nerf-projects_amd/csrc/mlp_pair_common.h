@@ -419,16 +419,31 @@ __device__ __forceinline__ P* wave_uniform(P* p) {
 }
 
 // Running maxima for the weight-gradient kernel's scales (MlpBwdLaunch::maxes: float bits, non-negative, so the integer
-// maximum is the float maximum): the wave's maximum by six DPP folds, and an atomic only when the slot does not hold as
-// much already - a thousand waves otherwise queue on one address per layer. The slot is read with a SCALAR load (glc: past
-// the scalar cache) from inline asm: left to hipcc the read became a vector load inside the lane-0 branch, whose
-// s_waitcnt vmcnt(0) drained the LDS-DMA weight ring once per layer.
-__device__ __forceinline__ void enter_max(unsigned* slot_uniform, float m_point, int lane) {
+// maximum is the float maximum): the wave's maximum by six DPP folds, compared with the largest value THIS wave has entered
+// so far (a word of LDS per wave and slot), and an atomic only when that record is broken - a thousand waves otherwise
+// queue on one address per layer. Nothing here touches the vector-memory counter or waits for it: the record lives in LDS
+// (inline asm: hipcc guards the LDS reads it can see with vmcnt(0) while an LDS-DMA is in flight), the atomic returns
+// nothing and is issued from inline asm (as a C++ atomicMax on this reconstructed pointer it became a FLAT atomic behind an
+// s_waitcnt vmcnt(0), which drained the weight ring).
+__device__ __forceinline__ void enter_max(unsigned* slot_uniform, unsigned* record_lds, float m_point, int lane) {
+#ifdef NERF_ABLATE_ENTER_MAX
+    return;
+#endif
+    const unsigned addr = lds_byte_addr(record_lds);
     unsigned known;
-    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(known) : "s"(slot_uniform) : "memory");
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(known) : "v"(addr) : "memory");
     const unsigned top = __float_as_uint(wave_max(m_point));
-    if (top > known && top < 0x7f800000u) {
-        if (lane == 0) atomicMax(slot_uniform, top);
+    if (top > (unsigned)__builtin_amdgcn_readfirstlane(known) && top < 0x7f800000u) {
+        if (lane == 0) {
+            const unsigned zero = 0u;
+            // (s_nop 4: the scalar base may have been written by a VECTOR instruction just before - a reloaded SGPR spill,
+            // v_readlane - and a vector-memory instruction must not read it for five wait states; hipcc inserts those for
+            // its own instructions only. tools/audit_lds_waits.py checks every vector-memory instruction for this.)
+            asm volatile("s_nop 4\n\tds_write_b32 %0, %1\n\tglobal_atomic_umax %2, %1, %3"
+                         :
+                         : "v"(addr), "v"(top), "v"(zero), "s"(slot_uniform)
+                         : "memory");
+        }
     }
 }
 

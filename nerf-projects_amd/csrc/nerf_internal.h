@@ -102,16 +102,20 @@ struct PackedNet {
     float* d_bias_h2 = nullptr;     // bias block of the equalised parameters
     bool h2_dirty = false;          // the master parameters changed (optimiser step): refresh before the next fp16-pair launch
     bool f32_dirty = false;         // likewise d_stream / d_bias (the fp32 kernels' inputs)
-    // e_j of every hidden unit ([kMaxLinears][256], 0 where rows are not scaled), written by the full equalisation. Between
-    // full passes (every kEqualiseEvery optimiser steps) the table is re-applied element-wise: any powers of two give the
-    // same function, and a few Adam steps move a row's norm by far less than a binade.
+    // e_j of every hidden unit ([kMaxLinears][256], 0 where rows are not scaled), chosen by every refresh_h2: the training step
+    // turns the equalised network's gradients into the plain parameters' with them (GradJob::ex)
     int* d_row_exp = nullptr;
-    int eq_age = 0;                 // optimiser steps since the exponents were chosen
     int n_chunks = 0;
     int n_bias_tiles = 0;
     uint32_t skip_in_mask = 0;   // bit i: trunk layer i reads [input_pts, h]
     int out_ch = 4;              // channels NeRF.forward returns
 };
+
+// nerf_ctx::d_loose: word 0 is the counter the precision guard watches (nerf_precision_status); words 1..7 a histogram of the
+// backward-data kernel's (wavefront, layer) events by how far the a-priori bound overshot: 2^12-13, 2^14-15, ..., >= 2^24
+// (nerf_precision_detail)
+constexpr int kLooseWords = 8;
+constexpr int kLooseBwdGuard = 1000;      // overshoot (in binades) from which a backward event also counts for the guard
 
 enum MlpInputMode { kInputEmbedded = 0, kInputPoints = 1, kInputRays = 2 };
 
@@ -238,13 +242,10 @@ struct EqualiseRefs {
     unsigned w_off[kMaxLinears], b_off[kMaxLinears];
     int scale_rows[kMaxLinears], col_src[kMaxLinears], hid_col0[kMaxLinears], n_hid[kMaxLinears];
 };
-// row_exp [kMaxLinears][256]: e_j of every linear (0 where rows are not scaled), written by the full pass and read back when
-// `reuse_exponents` (the element-wise re-application between full passes)
-hipError_t launch_equalise_rows(const float* params, const EqualiseRefs& refs, float* params_eq, int* row_exp,
-                                bool reuse_exponents, hipStream_t s);
+// row_exp [kMaxLinears][256]: e_j of every linear (0 where rows are not scaled): chosen, written out and applied
+hipError_t launch_equalise_rows(const float* params, const EqualiseRefs& refs, float* params_eq, int* row_exp, hipStream_t s);
 EqualiseRefs equalise_refs(const nerf_arch& arch, const std::vector<LinearDesc>& linears);
 struct PackedNet;
-constexpr int kEqualiseEvery = 32;
 // everything the fp16-pair kernel reads, rebuilt from the master parameters (api.cpp; at load and, lazily, after training steps)
 int refresh_h2(PackedNet& net, hipStream_t s);
 // the fp32 kernels' stream and bias block, likewise

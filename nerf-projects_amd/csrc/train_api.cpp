@@ -49,7 +49,6 @@ int mark_params_changed(PackedNet& net, hipStream_t s, bool stepped) {
     if (stepped) {
         net.f32_dirty = true;
         net.h2_dirty = true;
-        ++net.eq_age;                  // refresh_h2 chooses new exponents every kEqualiseEvery steps
     }
     net.train.bwd_dirty = true;
     return NERF_OK;

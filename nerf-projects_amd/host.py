@@ -63,6 +63,13 @@ class Context:
         check(self.lib.nerf_precision_status(self.handle, C.byref(n), int(bool(reset))))
         return n.value
 
+    def precision_detail(self, reset=True):
+        """[guard counter, then the backward-data kernel's events by overshoot 2^12-13, 2^14-15, ..., >= 2^24]
+        (nerf_precision_detail). Synchronises."""
+        v = (C.c_int64 * 8)()
+        check(self.lib.nerf_precision_detail(self.handle, v, int(bool(reset))))
+        return list(v)
+
     def precision_peek(self):
         """Loose-bound events of COMPLETED work that no call has reported yet (no synchronisation: a pinned mirror of the
         counter follows every render / training call). Marks them reported."""

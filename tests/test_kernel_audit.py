@@ -44,6 +44,10 @@ def test_no_register_touched_before_its_lds_wait(src, tmp_path):
         findings, n_ops, n_waits = audit.audit(str(out), inst)
         assert n_ops > min_ops and n_waits > min_waits, (inst, n_ops, n_waits)   # the kernel was found and parsed
         assert not findings, (inst, findings[:5])
+        # ... and no inline-asm store / atomic reads a scalar base a vector instruction (e.g. an SGPR-spill reload) has just
+        # written: the five wait states hipcc would insert for its own instructions (this was a GPU memory fault once)
+        hazards = audit.audit_sgpr_hazards(str(out), inst)
+        assert not hazards, (inst, hazards[:5])
     # no scratch: a spilled register is reloaded through the vector-memory counter, which the weight ring's waits own
     text = open(out).read()
     for inst in names:

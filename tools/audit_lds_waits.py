@@ -74,9 +74,68 @@ def audit(path, want="kernelILi2ELb0E"):
     return findings, n_reads, n_waits
 
 
+SREG = re.compile(r"\bs\[" + NUM + ":" + NUM + r"\]|\bs(\d+)\b")
+
+
+def sregs(text):
+    out = set()
+    for m in SREG.finditer(text):
+        if m.group(1):
+            out.update(range(int(m.group(1), 0), int(m.group(2), 0) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def audit_sgpr_hazards(path, want="kernelILi2ELb0E", need=5):
+    """A vector-memory instruction (the inline-asm stores / atomics / LDS-DMA with a scalar base) must not read a scalar
+    register that a VECTOR instruction (v_readlane, v_readfirstlane - e.g. the reload of a spilled SGPR - or a v_cmp into an
+    SGPR pair) wrote fewer than `need` wait states earlier: hipcc's hazard recogniser inserts those s_nops for its own
+    instructions but does not look inside inline asm. Returns the offending instructions."""
+    lines = open(path).read().split("\n")
+    findings, name = [], None
+    age = {}                       # sgpr -> wait states since a VALU wrote it
+    for no, raw in enumerate(lines, 1):
+        line = raw.split(";")[0].strip()
+        if not line:
+            continue
+        if line.endswith(":") and not line.startswith("."):
+            name, age = (line[:-1] if want in line else None), {}
+            continue
+        if name is None or line.startswith("."):
+            continue
+        if line.startswith("s_endpgm"):
+            name = None
+            continue
+        op, _, rest = line.partition(" ")
+        if op.startswith(("global_", "flat_", "buffer_", "scratch_")):
+            used = sregs(rest)
+            bad = sorted(r for r in used if age.get(r, 99) < need)
+            if bad:
+                findings.append((no, raw.strip(), [(r, age[r]) for r in bad]))
+        states = 1
+        if op == "s_nop":
+            states = int(rest.strip(), 0) + 1
+        for r in list(age):
+            age[r] += states
+        if op.startswith(("v_readlane", "v_readfirstlane")) or (op.startswith("v_cmp") and rest.lstrip().startswith("s[")) \
+                or (op.startswith(("v_add_co", "v_sub_co", "v_addc_co", "v_subb_co", "v_mad_u64", "v_mad_i64"))):
+            for r in sregs(rest.split(",")[0] if not op.startswith(("v_add_co", "v_sub_co", "v_addc_co", "v_subb_co", "v_mad")) else
+                           ",".join(rest.split(",")[:2])):
+                age[r] = 0
+        elif op.startswith("s_") and not op.startswith(("s_waitcnt", "s_nop", "s_barrier", "s_cbranch", "s_branch")):
+            for r in sregs(rest.split(",")[0]):
+                age.pop(r, None)    # a scalar instruction rewrote it: no hazard towards vector memory
+    return findings
+
+
 if __name__ == "__main__":
     f, r, w = audit(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "kernelILi2ELb0E")
     print(f"{sys.argv[1]}: {r} LDS operations, {w} lgkmcnt waits, {len(f)} accesses to registers still in flight")
     for no, text, which in f[:40]:
         print(f"  line {no}: {text}    <- {which}")
-    sys.exit(1 if f else 0)
+    hz = audit_sgpr_hazards(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "kernelILi2ELb0E")
+    print(f"{len(hz)} vector-memory instructions reading a scalar register a vector instruction has just written")
+    for no, text, which in hz[:40]:
+        print(f"  line {no}: {text}    <- (sgpr, wait states) {which}")
+    sys.exit(1 if (f or hz) else 0)
