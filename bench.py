@@ -203,8 +203,14 @@ def train_leg(N, synthetic, iters=30, warmup=5, n_rand=1024, Sc=64, Si=128):
               raw_noise_std=1.0, ndc=False, use_viewdirs=True, near=near, far=far)
     torch.manual_seed(0)
 
+    # batches as the reference's use_batching mode draws them (nerf.ipynb:1209-1230): one shuffle, consecutive windows
+    state = {"perm": torch.randperm(packed.shape[0], device="cuda"), "i_batch": 0}
+
     def one(i):
-        idx = torch.randperm(packed.shape[0], device="cuda")[:n_rand]
+        if state["i_batch"] + n_rand > packed.shape[0]:
+            state["perm"], state["i_batch"] = torch.randperm(packed.shape[0], device="cuda"), 0
+        idx = state["perm"][state["i_batch"]:state["i_batch"] + n_rand]
+        state["i_batch"] += n_rand
         r = packed[idx]
         target = torch.rand((n_rand, 3), device="cuda")
         out = N.train_on_batch(800, 800, K, (r[:, 0:3], r[:, 3:6]), target, opt, **kw)

@@ -159,16 +159,35 @@ int refresh_f32(PackedNet& net, hipStream_t s) {
     return NERF_OK;
 }
 
-int refresh_h2(PackedNet& net, hipStream_t s) {
-    HIP_TRY(launch_equalise_rows(net.d_params, equalise_refs(net.arch, net.linears), net.d_params_eq, net.d_row_exp, s));
-    HIP_TRY(launch_gather(net.d_params_eq, net.train.d_stream_table, (int64_t)net.stream_table.size(), net.d_stream_eq, s));
-    HIP_TRY(launch_gather(net.d_params_eq, net.train.d_bias_table, (int64_t)net.bias_table.size(), net.d_bias_h2, s));
-    HIP_TRY(launch_convert_stream_h2(net.d_stream_eq, net.d_chunk_layer, net.n_chunks, net.d_chunk_max, net.d_stream_h2,
-                                     net.d_descale, s));
-    HIP_TRY(launch_layer_gains(net.d_params_eq, gain_refs(net.arch, net.linears), net.d_gain, s));
-    net.h2_dirty = false;
-    if (net.train.bwd_is_eq) net.train.bwd_dirty = true;      // d_params_eq moved (also when only the exponents did)
+int refresh_h2_many(PackedNet* const* nets, int n, hipStream_t s) {
+    const float* params[2];
+    float* out[2];
+    int* rexp[2];
+    EqualiseRefs refs[2];
+    if (n < 1 || n > 2) return NERF_E_INVALID;
+    for (int i = 0; i < n; ++i) {
+        params[i] = nets[i]->d_params;
+        out[i] = nets[i]->d_params_eq;
+        rexp[i] = nets[i]->d_row_exp;
+        refs[i] = equalise_refs(nets[i]->arch, nets[i]->linears);
+    }
+    HIP_TRY(launch_equalise_rows(n, params, refs, out, rexp, s));
+    for (int i = 0; i < n; ++i) {
+        PackedNet& net = *nets[i];
+        HIP_TRY(launch_gather(net.d_params_eq, net.train.d_stream_table, (int64_t)net.stream_table.size(), net.d_stream_eq, s));
+        HIP_TRY(launch_gather(net.d_params_eq, net.train.d_bias_table, (int64_t)net.bias_table.size(), net.d_bias_h2, s));
+        HIP_TRY(launch_convert_stream_h2(net.d_stream_eq, net.d_chunk_layer, net.n_chunks, net.d_chunk_max, net.d_stream_h2,
+                                         net.d_descale, s));
+        HIP_TRY(launch_layer_gains(net.d_params_eq, gain_refs(net.arch, net.linears), net.d_gain, s));
+        net.h2_dirty = false;
+        if (net.train.bwd_is_eq) net.train.bwd_dirty = true;      // d_params_eq moved
+    }
     return NERF_OK;
+}
+
+int refresh_h2(PackedNet& net, hipStream_t s) {
+    PackedNet* one = &net;
+    return refresh_h2_many(&one, 1, s);
 }
 
 GainRefs gain_refs(const nerf_arch& a, const std::vector<LinearDesc>& linears) {

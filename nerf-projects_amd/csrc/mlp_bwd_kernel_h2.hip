@@ -45,8 +45,8 @@ template <int T, int S>
 __device__ __forceinline__ void bconv0(ConvTmp& t, const f32x16& src, const PendingB& pd) {
     const unsigned w = pd.mask[T >> 1];
     const float g0 = src[2 * S] * pd.c, g1 = src[2 * S + 1] * pd.c;
-    t.y0 = __uint_as_float(__float_as_uint(g0) & mask_of<T, S, 0>(w));
-    t.y1 = __uint_as_float(__float_as_uint(g1) & mask_of<T, S, 1>(w));
+    t.y0 = mask_apply<T, S, 0>(w, g0);
+    t.y1 = mask_apply<T, S, 1>(w, g1);
 }
 __device__ __forceinline__ void bconv1(ConvTmp& t, PendingB& pd) {
     pd.m = fmaxf(fmaxf(pd.m, fabsf(t.y0)), fabsf(t.y1));
@@ -112,7 +112,8 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
     //   [0] d raw of the tile (one tile ahead)   [1] the view layer's mask (one tile ahead)   [2] a trunk layer's mask (requested
     //   when the layer's chunks begin, read when they end)
     __shared__ __attribute__((aligned(16))) char pre_lds[kWavesPerGroup][3][kPreSlotBytes];
-    __shared__ unsigned max_record[kWavesPerGroup][kBwdMaxSlots];      // enter_max: what each wave has entered so far
+    __shared__ unsigned max_record[kBwdMaxSlots];                      // enter_max: this workgroup's maxima, flushed at the end
+    __shared__ unsigned loose_hist[kLooseWords];                       // this workgroup's loose-bound events, flushed at the end
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
@@ -127,7 +128,8 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
     prefetch_pieces<0, 4>(piece_src(pipe, 2), piece_dst(pipe, 2));   // chunk 0's first-half steps issue the other four
     // rgb_linear's rows: bias-block tiles 8D+22 .. 8D+33 (pack_weights.cpp row_tiles)
     for (int i = threadIdx.x; i < kRgbRowFloats; i += 256) rgb_lds[i] = b.bias[(8 * D + 22) * kBiasTileFloats + i];
-    if (threadIdx.x < kWavesPerGroup * kBwdMaxSlots) (&max_record[0][0])[threadIdx.x] = 0u;
+    if (threadIdx.x < kBwdMaxSlots) max_record[threadIdx.x] = 0u;
+    if (threadIdx.x < kLooseWords) loose_hist[threadIdx.x] = 0u;
     if ((int)threadIdx.x <= D) {
         const int l = threadIdx.x;
         layer_tab[4 * l] = b.descale[l];
@@ -213,7 +215,7 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
                 }
             }
             m_prev = half_max(m);
-            if (b.maxes) enter_max(wave_uniform(b.maxes + kBwdMaxViews), &max_record[wave][kBwdMaxViews], m_prev, lane);
+            enter_max(&max_record[kBwdMaxViews], m_prev);
             const int t_v = pick_exponent(m_prev);
             const float sc = pow2f(t_v);
 #pragma unroll
@@ -253,12 +255,15 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
             // (nerf_precision_detail); from 2^kLooseBwdGuard on also where the precision guard looks.
             const float m_grp = slot == kBwdMaxFeat ? fmaxf(m_prev, dsig_abs) : m_prev;
             const int slack = 10 - pd.t_out - __builtin_amdgcn_frexp_expf(m_grp);
-            if (m_grp > 0.0f && slack >= 12 && pd.t_out > -60 && b.loose) {
+            // Into LDS (a per-lane atomic on eight global addresses, a quarter of all lanes firing, queued in the memory pipe
+            // the weight ring's counted waits look at: it doubled the kernel's time); the workgroup adds its sums at the end.
+            if (m_grp > 0.0f && slack >= 12 && pd.t_out > -60) {
                 const int bucket = 1 + (slack >= 24 ? 6 : (slack - 12) >> 1);
-                atomicAdd(b.loose + bucket, 1u);
-                if (slack >= kLooseBwdGuard) atomicAdd(b.loose, 1u);
+                const unsigned one = 1u;
+                asm volatile("ds_add_u32 %0, %1" : : "v"(lds_byte_addr(loose_hist + bucket)), "v"(one) : "memory");
+                if (slack >= kLooseBwdGuard) asm volatile("ds_add_u32 %0, %1" : : "v"(lds_byte_addr(loose_hist)), "v"(one) : "memory");
             }
-            if (b.maxes && slot >= 0) enter_max(wave_uniform(b.maxes + slot), &max_record[wave][slot], m_prev, lane);
+            if (slot >= 0) enter_max(&max_record[slot], m_prev);
         };
 
         // ---- d feature = W_views[:, :W]^T d(view pre-activation): four k-tiles, nothing pending yet ----
@@ -323,7 +328,10 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
         bconvert_tile<6, false>(hid[0], accA[6], pd);
         bconvert_tile<7, false>(hid[0], accA[7], pd);
     }   // tile loop
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (b.loose && threadIdx.x < kLooseWords && loose_hist[threadIdx.x]) atomicAdd(b.loose + threadIdx.x, loose_hist[threadIdx.x]);
+    flush_maxes(b.maxes, max_record, kBwdMaxSlots);
 }
 
 hipError_t launch_mlp_bwd_h2(const MlpBwdLaunch& b, hipStream_t s) {
@@ -367,20 +375,36 @@ hipError_t launch_mlp_bwd_h2(const MlpBwdLaunch& b, hipStream_t s) {
 // gain[2b] = largest row sum of |W^T| of backward layer b (= largest column sum of |W| over the block the layer
 // contracts), gain[2b + 1] = largest |alpha weight| for b = 1. One workgroup per layer, a thread per column (coalesced
 // along the rows of W).
-__global__ __launch_bounds__(256) void layer_gain_bwd_kernel(const float* params, const BwdGainRefs refs, float* gain) {
+__global__ __launch_bounds__(1024) void layer_gain_bwd_kernel(const float* params, const BwdGainRefs refs, float* gain) {
+    __shared__ float part[4][256];
     __shared__ float red[2][4];
-    const int l = blockIdx.x, r = threadIdx.x;
+    const int l = blockIdx.x, r = threadIdx.x & 255, q = threadIdx.x >> 8;      // column r, row quarter q
     const float* w = params + refs.w_off[l] + refs.col0[l] + r;
+    const int n_rows = refs.rows[l], per = (n_rows + 3) / 4;
     float sum = 0.0f;
-    for (int c = 0; c < refs.rows[l]; ++c) sum += fabsf(w[(size_t)c * refs.ld[l]]);
-    float am = (l == 1) ? fabsf(params[refs.alpha_off + r]) : 0.0f;
-    for (int o = 32; o > 0; o >>= 1) {
-        sum = fmaxf(sum, __shfl_xor(sum, o));
-        am = fmaxf(am, __shfl_xor(am, o));
+    for (int c0 = q * per; c0 < (q + 1) * per; c0 += 8) {      // eight loads in flight
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u;
+            v[u] = (c < (q + 1) * per && c < n_rows) ? w[(size_t)c * refs.ld[l]] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += fabsf(v[u]);
     }
-    if ((threadIdx.x & 63) == 0) {
-        red[0][threadIdx.x >> 6] = sum;
-        red[1][threadIdx.x >> 6] = am;
+    part[q][r] = sum;
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        sum = part[0][r] + part[1][r] + part[2][r] + part[3][r];
+        float am = (l == 1) ? fabsf(params[refs.alpha_off + r]) : 0.0f;
+        for (int o = 32; o > 0; o >>= 1) {
+            sum = fmaxf(sum, __shfl_xor(sum, o));
+            am = fmaxf(am, __shfl_xor(am, o));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            red[0][threadIdx.x >> 6] = sum;
+            red[1][threadIdx.x >> 6] = am;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -411,7 +435,7 @@ BwdGainRefs bwd_gain_refs(const nerf_arch& a, const std::vector<LinearDesc>& lin
 
 hipError_t launch_layer_gains_bwd(const float* params, const BwdGainRefs& refs, float* gain, hipStream_t s) {
     if (refs.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(layer_gain_bwd_kernel, dim3(refs.n), dim3(256), 0, s, params, refs, gain);
+    hipLaunchKernelGGL(layer_gain_bwd_kernel, dim3(refs.n), dim3(1024), 0, s, params, refs, gain);
     return hipGetLastError();
 }
 

@@ -63,8 +63,10 @@ struct Pending {
     unsigned keep_off;     // ... and this lane's BYTE offset of (its point, feature 4 h) in it
     f32x2 even;            // (convert_pair: the even pair of a register quad, until the odd one completes the 16 bytes)
     unsigned* mask_base;   // STORE kernels: this layer's ReLU-mask record (MlpStore::mask), this lane's BYTE offset in it,
-    unsigned mask_off;     // and the word being collected (mask_push)
-    unsigned maskw;
+    unsigned mask_off;     // the word being collected (mask_push) and the record's finished words: the record goes out as
+    unsigned maskw;        // ONE 16-byte store when the layer is closed (a wave then writes a contiguous KiB; word by word,
+    u32x4 maskq;           // 4-byte pieces of a line reached memory microseconds apart - partial-line writes - and cost
+                           // the pass a fifth of its time)
 };
 
 // Training forward (STORE kernels): register pair P of tile T of the pending layer - features 32 T + 8 (P/2) + 2 (P%2) + 4 h
@@ -125,7 +127,7 @@ __device__ __forceinline__ void convert_pair(XT& dst, const f32x16& src, Pending
     if constexpr (STORE) {
         pd.maskw = mask_push(pd.maskw, hi);
         if constexpr (P == 7 && (T & 1) == 1) {      // tiles 2w, 2w + 1 done: word w of the record
-            keep_word<4 * (T >> 1)>(pd.mask_base, pd.mask_off, pd.maskw);
+            pd.maskq[T >> 1] = pd.maskw;
             pd.maskw = 0u;
         }
     }
@@ -201,7 +203,7 @@ __device__ __forceinline__ void chunk_ktile8(PipeH& p, Frag4& cur, f32x16 (&acc)
                 if constexpr (STORE) {      // the pair's ReLU flags (MlpStore::mask)
                     pd.maskw = mask_push(pd.maskw, hid[C0].hi[s >> 2][s & 3]);
                     if constexpr (s == 7 && (C0 & 1) == 1) {
-                        keep_word<4 * (C0 >> 1)>(pd.mask_base, pd.mask_off, pd.maskw);
+                        pd.maskq[C0 >> 1] = pd.maskw;
                         pd.maskw = 0u;
                     }
                 }
@@ -334,7 +336,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
     extern __shared__ __attribute__((aligned(16))) char ring_lds[];
     __shared__ __attribute__((aligned(16))) float bias_lds[kBiasLdsBytes / 4];
     __shared__ __attribute__((aligned(16))) float layer_tab[4 * (kMaxDepth + 3)];   // per layer [descale, gain, max|b|, -]
-    __shared__ unsigned max_record[STORE ? kWavesPerGroup : 1][kBwdMaxSlots];      // STORE: enter_max's per-wave records
+    __shared__ unsigned max_record[kBwdMaxSlots];      // STORE: enter_max's records
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
@@ -350,7 +352,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
     }
     prefetch_pieces<0, 4>(piece_src(pipe, 2), piece_dst(pipe, 2));   // chunk 0's first-half steps issue the other four
     for (int i = threadIdx.x; i < a.n_bias_tiles * kBiasTileFloats; i += 256) bias_lds[i] = a.bias[i];
-    if (STORE && threadIdx.x < kWavesPerGroup * kBwdMaxSlots) (&max_record[0][0])[threadIdx.x] = 0u;
+    if (STORE && threadIdx.x < kBwdMaxSlots) max_record[threadIdx.x] = 0u;
     if (threadIdx.x < a.D + 3) {
         const int l = threadIdx.x;
         const bool has_gain = l <= (a.use_viewdirs ? a.D : a.D - 1);
@@ -437,8 +439,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             pd.m = 0.0f;
             if constexpr (STORE) {
                 pd.maskw = 0u;
-                // (feature_linear has no ReLU: what its tiles 0, 1 collect goes to the unused third word of the view layer's record)
-                pd.mask_base = is_feature ? a.st.mask_hv + 2 : a.st.mask[l];
+                pd.mask_base = wave_uniform(is_feature ? a.st.mask_hv : a.st.mask[l]);      // (feature_linear: not written)
                 pd.mask_off = 16u * (2u * (unsigned)pt + (unsigned)h);
                 pd.keep_base = is_feature ? a.st.feat : a.st.h[l];
                 pd.keep_off = 4u * ((unsigned)pt * (unsigned)(is_feature ? a.st.feat_ld : a.st.h_ld[l]) + 4u * (unsigned)h);
@@ -457,8 +458,12 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
         auto close_pending = [&](int slot) {
             m_prev = half_max(pd.m);
             if constexpr (STORE) {
+                // this layer's ReLU-mask record (for feature_linear, which has no ReLU, the buffer is nullptr-free scratch:
+                // see make_pending)
+                if (slot != kBwdMaxFeatValue)
+                    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(pd.mask_off), "v"(pd.maskq), "s"(pd.mask_base) : "memory");
                 // the largest kept activation of this layer, for the weight-gradient kernel's scale (MlpStore::maxes)
-                enter_max(wave_uniform(a.st.maxes + slot), &max_record[wave][slot], m_prev, lane);
+                enter_max(&max_record[slot], m_prev);
             }
             // the scale was chosen for a bound of 2^(10 - t_out); outputs 2^12 and more below it have begun to lose
             // low-half bits (see Pending). Counted, never silent: nerf_precision_status.
@@ -549,8 +554,8 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
                 keep_tiles4<0>(a.st.hv, off, y);
                 // the view layer's ReLU mask in the bit order of the trunk layers' (MlpStore::mask_hv, words 0 and 1)
                 const unsigned moff = 16u * (2u * (unsigned)pt + (unsigned)h);
-                keep_word<0>(a.st.mask_hv, moff, relu_mask_word(y[0], y[1]));
-                keep_word<4>(a.st.mask_hv, moff, relu_mask_word(y[2], y[3]));
+                const u32x4 rec = {relu_mask_word(y[0], y[1]), relu_mask_word(y[2], y[3]), 0u, 0u};
+                asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(moff), "v"(rec), "s"(a.st.mask_hv) : "memory");
             }
             // rgb_linear (nerf.py:101): three rows over the 128-wide view layer
             const float* rb = bias_lds + (8 * a.D + 13) * 32;
@@ -599,7 +604,11 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
         pipe.st.on = false;   // first tile only
 #endif
     }   // tile loop
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if constexpr (STORE) {
+        __syncthreads();
+        flush_maxes(a.st.maxes, max_record, kBwdMaxSlots);
+    }
 }
 
 hipError_t launch_mlp_h2(const MlpLaunch& a, int mode, hipStream_t s) {
@@ -765,7 +774,17 @@ __global__ __launch_bounds__(256) void layer_gain_kernel(const float* params, co
 // writes the equalised copy element-wise, every row of every layer at once. (One kernel doing both on one workgroup took
 // 0.4 ms per network; the training step equalises both networks after every optimiser step, so that a step stays a
 // function of the parameters alone - a resumed run repeats the original bit for bit.)
-__global__ __launch_bounds__(1024) void row_exponents_kernel(const float* params, const EqualiseRefs r, int* row_exp_out) {
+struct EqualiseBatch {
+    int n;
+    const float* params[2];
+    int* row_exp[2];
+    float* out[2];
+    EqualiseRefs refs[2];
+};
+__global__ __launch_bounds__(1024) void row_exponents_kernel(const EqualiseBatch batch) {
+    const float* params = batch.params[blockIdx.x];
+    int* row_exp_out = batch.row_exp[blockIdx.x];
+    const EqualiseRefs& r = batch.refs[blockIdx.x];
     __shared__ int expo[kMaxLinears][256];    // e_j of every linear (0 where rows are not scaled)
     __shared__ int row_exp[256];              // binade of a row's norm, -1000: leave the row alone
     constexpr int kExpBins = 320;             // frexp exponents of finite floats lie within -148 .. 128
@@ -781,7 +800,7 @@ __global__ __launch_bounds__(1024) void row_exponents_kernel(const float* params
             // sum 256) - rows of zeros with a zero bias and non-finite rows keep factor 1
             for (int q = threadIdx.x; q < kExpBins; q += blockDim.x) hist[q] = 0;
             if (threadIdx.x == 0) n_valid = 0;
-            constexpr int kRows = 4, kCols = 6;        // rows per wave and round; 64 x 6 = 384 columns cover in <= 383
+            constexpr int kRows = 8, kCols = 6;        // rows per wave and round; 64 x 6 = 384 columns cover in <= 383
             for (int j0 = wave * kRows; j0 < n_out; j0 += n_waves * kRows) {
                 float v[kRows][kCols];
 #pragma unroll
@@ -864,8 +883,11 @@ __global__ __launch_bounds__(1024) void row_exponents_kernel(const float* params
 
 // out[k][j][c] = params[k][j][c] * 2^(e_kj - e_src(k),c) (row_exponents_kernel's table; exact): the copy of the network the
 // fp16-pair kernels evaluate. Grid (row block of 4, linear); a wavefront per row.
-__global__ __launch_bounds__(256) void apply_row_exponents_kernel(const float* params, const EqualiseRefs r,
-                                                                  const int* row_exp, float* out) {
+__global__ __launch_bounds__(256) void apply_row_exponents_kernel(const EqualiseBatch batch) {
+    const float* params = batch.params[blockIdx.z];
+    const int* row_exp = batch.row_exp[blockIdx.z];
+    float* out = batch.out[blockIdx.z];
+    const EqualiseRefs& r = batch.refs[blockIdx.z];
     const int k = blockIdx.y, lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= r.n || j >= r.out[k]) return;
     const int n_in = r.in[k], src = r.col_src[k], c0 = r.hid_col0[k], c1 = c0 + r.n_hid[k];
@@ -879,16 +901,26 @@ __global__ __launch_bounds__(256) void apply_row_exponents_kernel(const float* p
     if (lane == 0) out[r.b_off[k] + j] = __builtin_ldexpf(params[r.b_off[k] + j], e);
 }
 
-hipError_t launch_equalise_rows(const float* params, const EqualiseRefs& refs, float* params_eq, int* row_exp, hipStream_t s) {
-    if (refs.n <= 0 || refs.n > kMaxLinears || !row_exp) return hipErrorInvalidValue;
-    int max_out = 1;
-    for (int k = 0; k < refs.n; ++k) {
-        if (refs.out[k] > 256 || refs.in[k] > 383) return hipErrorInvalidValue;
-        max_out = refs.out[k] > max_out ? refs.out[k] : max_out;
+hipError_t launch_equalise_rows(int n, const float* const* params, const EqualiseRefs* refs, float* const* params_eq,
+                                int* const* row_exp, hipStream_t s) {
+    if (n < 1 || n > 2) return hipErrorInvalidValue;
+    EqualiseBatch b{};
+    b.n = n;
+    int max_out = 1, max_n = 1;
+    for (int i = 0; i < n; ++i) {
+        if (refs[i].n <= 0 || refs[i].n > kMaxLinears || !row_exp[i] || !params[i] || !params_eq[i]) return hipErrorInvalidValue;
+        for (int k = 0; k < refs[i].n; ++k) {
+            if (refs[i].out[k] > 256 || refs[i].in[k] > 383) return hipErrorInvalidValue;
+            max_out = refs[i].out[k] > max_out ? refs[i].out[k] : max_out;
+        }
+        max_n = refs[i].n > max_n ? refs[i].n : max_n;
+        b.params[i] = params[i];
+        b.row_exp[i] = row_exp[i];
+        b.out[i] = params_eq[i];
+        b.refs[i] = refs[i];
     }
-    hipLaunchKernelGGL(row_exponents_kernel, dim3(1), dim3(1024), 0, s, params, refs, row_exp);
-    hipLaunchKernelGGL(apply_row_exponents_kernel, dim3((max_out + 3) / 4, refs.n), dim3(256), 0, s, params, refs, row_exp,
-                       params_eq);
+    hipLaunchKernelGGL(row_exponents_kernel, dim3(n), dim3(1024), 0, s, b);
+    hipLaunchKernelGGL(apply_row_exponents_kernel, dim3((max_out + 3) / 4, max_n, n), dim3(256), 0, s, b);
     return hipGetLastError();
 }
 

@@ -419,31 +419,24 @@ __device__ __forceinline__ P* wave_uniform(P* p) {
 }
 
 // Running maxima for the weight-gradient kernel's scales (MlpBwdLaunch::maxes: float bits, non-negative, so the integer
-// maximum is the float maximum): the wave's maximum by six DPP folds, compared with the largest value THIS wave has entered
-// so far (a word of LDS per wave and slot), and an atomic only when that record is broken - a thousand waves otherwise
-// queue on one address per layer. Nothing here touches the vector-memory counter or waits for it: the record lives in LDS
-// (inline asm: hipcc guards the LDS reads it can see with vmcnt(0) while an LDS-DMA is in flight), the atomic returns
-// nothing and is issued from inline asm (as a C++ atomicMax on this reconstructed pointer it became a FLAT atomic behind an
-// s_waitcnt vmcnt(0), which drained the weight ring).
-__device__ __forceinline__ void enter_max(unsigned* slot_uniform, unsigned* record_lds, float m_point, int lane) {
+// maximum is the float maximum). A lane hands its point's maximum to an LDS atomic on the workgroup's record - one
+// instruction, nothing returned, nothing waited for - and the workgroup enters its records into the global slots when it
+// ends (flush_maxes). Earlier forms and what they cost the training forward pass: a C++ atomicMax per wave and layer (a
+// thousand waves queue on one address); a wave reduction by DPP folds plus a compare against the slot read through the
+// scalar cache (6 % of the pass: all of it in the open at a layer boundary); the same with a C++ atomicMax on a
+// reconstructed pointer (a FLAT atomic behind s_waitcnt vmcnt(0): the weight ring drained at every boundary, 2x).
+__device__ __forceinline__ void enter_max(unsigned* record_lds, float m_point) {
 #ifdef NERF_ABLATE_ENTER_MAX
     return;
 #endif
-    const unsigned addr = lds_byte_addr(record_lds);
-    unsigned known;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(known) : "v"(addr) : "memory");
-    const unsigned top = __float_as_uint(wave_max(m_point));
-    if (top > (unsigned)__builtin_amdgcn_readfirstlane(known) && top < 0x7f800000u) {
-        if (lane == 0) {
-            const unsigned zero = 0u;
-            // (s_nop 4: the scalar base may have been written by a VECTOR instruction just before - a reloaded SGPR spill,
-            // v_readlane - and a vector-memory instruction must not read it for five wait states; hipcc inserts those for
-            // its own instructions only. tools/audit_lds_waits.py checks every vector-memory instruction for this.)
-            asm volatile("s_nop 4\n\tds_write_b32 %0, %1\n\tglobal_atomic_umax %2, %1, %3"
-                         :
-                         : "v"(addr), "v"(top), "v"(zero), "s"(slot_uniform)
-                         : "memory");
-        }
+    asm volatile("ds_max_u32 %0, %1" : : "v"(lds_byte_addr(record_lds)), "v"(__float_as_uint(m_point)) : "memory");
+}
+// at the end of the kernel, behind a barrier: thread t enters record t
+__device__ __forceinline__ void flush_maxes(unsigned* global_slots, const unsigned* record_lds, int n) {
+    const int t = threadIdx.x;
+    if (global_slots && t < n) {
+        const unsigned v = record_lds[t];
+        if (v != 0u && v < 0x7f800000u) atomicMax(global_slots + t, v);
     }
 }
 
@@ -472,11 +465,15 @@ __device__ __forceinline__ unsigned mask_push(unsigned field, unsigned hi) {
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(hi), "s"(0x00010001u));
     return (field << 1) | t;
 }
-// all ones where the bit is set: value 2s (ODD = 0) / 2s + 1 (ODD = 1) of tile T, from the word of tiles 2 (T / 2), + 1
+// g where the unit's bit is set, else 0: value 2s (ODD = 0) / 2s + 1 (ODD = 1) of tile T, from the word of tiles 2 (T / 2), + 1.
+// Two instructions from inline asm (the bit sign-extended to a mask, then an AND): from C++ hipcc makes it an AND, a
+// compare into vcc, a wait state and a select.
 template <int T, int S, int ODD>
-__device__ __forceinline__ unsigned mask_of(unsigned word) {
+__device__ __forceinline__ float mask_apply(unsigned word, float g) {
     constexpr int bit = (ODD ? 31 : 15) - 8 * (T & 1) - S;
-    return (unsigned)__builtin_amdgcn_sbfe(word, bit, 1);
+    float y;
+    asm("v_bfe_i32 %0, %1, %2, 1\n\tv_and_b32 %0, %0, %3" : "=&v"(y) : "v"(word), "n"(bit), "v"(g));
+    return y;
 }
 
 }  // namespace nerf

@@ -115,7 +115,8 @@ struct PackedNet {
 // backward-data kernel's (wavefront, layer) events by how far the a-priori bound overshot: 2^12-13, 2^14-15, ..., >= 2^24
 // (nerf_precision_detail)
 constexpr int kLooseWords = 8;
-constexpr int kLooseBwdGuard = 1000;      // overshoot (in binades) from which a backward event also counts for the guard
+constexpr int kLooseBwdGuard = 1000;    // overshoot (in binades) from which a backward event would also count for the guard:
+                                        // never (nerf_mi355x.h, nerf_precision_detail, says why)
 
 enum MlpInputMode { kInputEmbedded = 0, kInputPoints = 1, kInputRays = 2 };
 
@@ -242,12 +243,15 @@ struct EqualiseRefs {
     unsigned w_off[kMaxLinears], b_off[kMaxLinears];
     int scale_rows[kMaxLinears], col_src[kMaxLinears], hid_col0[kMaxLinears], n_hid[kMaxLinears];
 };
-// row_exp [kMaxLinears][256]: e_j of every linear (0 where rows are not scaled): chosen, written out and applied
-hipError_t launch_equalise_rows(const float* params, const EqualiseRefs& refs, float* params_eq, int* row_exp, hipStream_t s);
+// row_exp [kMaxLinears][256]: e_j of every linear (0 where rows are not scaled): chosen, written out and applied - for one
+// network or two in the same pair of launches (the training step equalises the coarse and the fine network together)
+hipError_t launch_equalise_rows(int n, const float* const* params, const EqualiseRefs* refs, float* const* params_eq,
+                                int* const* row_exp, hipStream_t s);
 EqualiseRefs equalise_refs(const nerf_arch& arch, const std::vector<LinearDesc>& linears);
 struct PackedNet;
 // everything the fp16-pair kernel reads, rebuilt from the master parameters (api.cpp; at load and, lazily, after training steps)
 int refresh_h2(PackedNet& net, hipStream_t s);
+int refresh_h2_many(PackedNet* const* nets, int n, hipStream_t s);
 // the fp32 kernels' stream and bias block, likewise
 int refresh_f32(PackedNet& net, hipStream_t s);
 hipError_t launch_convert_stream_h2(const float* stream, const int* chunk_layer, int n_chunks, float* chunk_max,

@@ -756,6 +756,13 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
             if ((rc = mark_params_changed(*n, s, true))) return rc;
             if (!Si || shared) break;
         }
+        // the equalised copies of both networks follow at once (one pair of launches for the two): the next step - or a
+        // render - needs them anyway
+        if (pc.eq) {
+            PackedNet* both[2] = {&nc, &nf};
+            const int n_nets = (Si && !shared) ? 2 : 1;
+            if ((rc = refresh_h2_many(both, n_nets, s))) return rc;
+        }
     }
     HIP_TRY(mirror_loose(c, s));
     if (fell_back) {
