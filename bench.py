@@ -220,24 +220,58 @@ def train_leg(N, synthetic, iters=30, warmup=5, n_rand=1024, Sc=64, Si=128):
     for i in range(warmup):
         one(i)
     torch.cuda.synchronize()
+    ctx = N.get_context()
     t0 = time.perf_counter()
     for i in range(iters):
         out = one(i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the step's kernels, each against the roofline of the pipe it runs on (HIP events on the step's stream, a second short
+    # run after the timed one: the events are not inside the reported it/s)
+    ctx.profile_enable(True)
+    ctx.profile_read_train(reset=True)
+    n_prof = 10
+    for i in range(n_prof):
+        one(i)
+    torch.cuda.synchronize()
+    ctx.profile_enable(False)
+    spans = ctx.profile_read_train(reset=True)
+    pair = ctx.get_precision() == "f16x2"
+    env = lambda k: os.environ.get(k, "").lower().startswith("f3")
+    pair_forward, pair_bwd, pair_dw = (pair and not env("NERF_TRAIN_FORWARD"), pair and not env("NERF_TRAIN_FORWARD") and
+                                       not env("NERF_TRAIN_BWD"), pair and not env("NERF_TRAIN_DW"))
+    # algorithmic FLOP per point: forward 2 x 593 408; backward-data 2 x (128 x 256 + 256 x 256 + 256 + 7 x 256 x 256 + 3 x 128);
+    # hidden-width weight gradients 2 x (8 x 256 x 256 + 128 x 256); they read dY and X once per job: 10 jobs x 2 KB per point
+    flop = {"forward": FLOP_PER_EVAL, "backward_data": 2 * (128 * 256 + 256 * 256 + 256 + 7 * 256 * 256 + 3 * 128),
+            "weight_gradients_hidden": 2 * (8 * 256 * 256 + 128 * 256)}
+    pipe_pair, pipe_f32 = PEAK_FP16_MFMA_TFLOPS / 3, PEAK_FP32_MFMA_TFLOPS
+    kernels = {}
+    for name, on_pair in (("forward", pair_forward), ("backward_data", pair_bwd), ("weight_gradients_hidden", pair_dw)):
+        ms, launches, pts = spans[name]
+        if launches == 0:
+            continue
+        tf = pts * flop[name] / (ms * 1e-3) / 1e12
+        peak = pipe_pair if on_pair else pipe_f32
+        k = {"ms_per_iter": ms / n_prof, "tflops": tf, "pipe": "f16 (3 products per term)" if on_pair else "f32",
+             "pipe_peak_tflops": peak, "frac_of_pipe_peak": tf / peak}
+        if name == "weight_gradients_hidden":
+            gbs = pts * 10 * 2048 / (ms * 1e-3) / 1e9      # (incl. the slice reductions; every operand byte is read once)
+            k.update(hbm_gb_per_s=gbs, frac_of_hbm_peak=gbs / 8000.0, bound="hbm" if on_pair else "mfma")
+        kernels[name] = k
+    ms_o, _, _ = spans["weight_gradients_other"]
+    kernels["weight_gradients_other"] = {"ms_per_iter": ms_o / n_prof, "pipe": "f32"}
     evals = n_rand * (Sc + Sc + Si)
     tf = evals * FLOP_PER_EVAL * 3 * iters / dt / 1e12          # forward + dX + dW
-    pair_forward = (N.get_context().get_precision() == "f16x2" and
-                    not os.environ.get("NERF_TRAIN_FORWARD", "").lower().startswith("f3"))
-    pair_dw = (N.get_context().get_precision() == "f16x2" and
-               not os.environ.get("NERF_TRAIN_DW", "").lower().startswith("f3"))
     return {"metric": "train_iterations_per_sec", "value": iters / dt, "unit": "it/s", "iters": iters,
             "ms_per_iter": dt / iters * 1e3, "n_rand": n_rand, "N_samples": Sc, "N_importance": Si,
-            "tflops_effective": tf, "frac_of_fp32_mfma_peak": tf / PEAK_FP32_MFMA_TFLOPS,
-            "arithmetic": ("forward: fp16-pair kernel (3 x v_mfma_f32_32x32x16_f16 per term, fp32 accumulate, fp32-level error); "
-                           if pair_forward else "forward: f32; ") +
-                          ("hidden-width weight gradients: fp16-pair; " if pair_dw else "") +
-                          "backward-data, other weight gradients, Adam: f32 (v_mfma_f32_32x32x2_f32), fp32 master weights",
+            "tflops_effective": tf, "kernels": kernels,
+            "arithmetic": ("forward, backward-data and the hidden-width weight gradients: fp16-pair kernels on the row-equalised "
+                           "network (3 x v_mfma_f32_32x32x16_f16 per term, fp32 accumulate, fp32-level error); "
+                           if (pair_forward and pair_bwd and pair_dw) else
+                           f"forward: {'fp16-pair' if pair_forward else 'f32'}; backward-data: {'fp16-pair' if pair_bwd else 'f32'}; "
+                           f"hidden-width weight gradients: {'fp16-pair' if pair_dw else 'f32'}; ") +
+                          "other weight gradients, compositing, Adam: f32, fp32 master weights",
+            "batches": "use_batching windows of one shuffle (nerf.ipynb:1209-1230)",
             "final_loss": float(out["loss"]),
             "reference_stored_run": "5.6-7.4 it/s (ship 96+192, unknown CUDA GPU; BASELINE.md section 1)"}
 

@@ -377,6 +377,12 @@ int nerf_profile_enable(nerf_ctx* ctx, int on);
 int nerf_profile_read(nerf_ctx* ctx, double* mlp_ms, int64_t* mlp_launches,
                       int64_t* mlp_points, int reset);
 
+/* The same for the training step's kernels (HIP events on the step's stream while profiling is enabled), summed by kind:
+ * [0] the forward passes' fused launches, [1] the backward-data launches, [2] the hidden-width weight-gradient launches
+ * with their slice reductions, [3] the other weight gradients. ms / launches / points are [4] arrays (NULL = not wanted). */
+int nerf_profile_read_train(nerf_ctx* ctx, double* ms /*[host] [4]*/, int64_t* launches /*[host] [4]*/,
+                            int64_t* points /*[host] [4]*/, int reset);
+
 /* Bytes of device workspace currently held by the context. */
 int64_t nerf_workspace_bytes(nerf_ctx* ctx);
 

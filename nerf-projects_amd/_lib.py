@@ -20,7 +20,7 @@ EXPORTS = (
     "nerf_get_gradients", "nerf_stratified_z", "nerf_resample", "nerf_render_frame", "nerf_set_precision",
     "nerf_get_precision", "nerf_precision_status", "nerf_get_adam_state", "nerf_set_adam_state",
     "nerf_shard_bounds", "nerf_render_shard", "nerf_precision_peek", "nerf_precision_check",
-    "nerf_precision_detail",
+    "nerf_precision_detail", "nerf_profile_read_train",
 )
 NERF_W_PRECISION, NERF_W_PRECISION_FALLBACK = 1, 2
 NERF_GUARD_OFF, NERF_GUARD_REPORT, NERF_GUARD_FALLBACK = 0, 1, 2
@@ -118,6 +118,8 @@ def load():
     lib.nerf_profile_enable.argtypes = [vp, i32]
     lib.nerf_profile_read.restype = i32
     lib.nerf_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64), i32]
+    lib.nerf_profile_read_train.restype = i32
+    lib.nerf_profile_read_train.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64), i32]
     lib.nerf_generate_rays.restype = i32
     lib.nerf_generate_rays.argtypes = [vp, C.POINTER(Camera), i64, i64, vp, vp]
     lib.nerf_image_metrics.restype = i32

@@ -334,6 +334,10 @@ void nerf_ctx_destroy(nerf_ctx* c) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
     }
+    for (auto& sp : c->train_spans) {
+        (void)hipEventDestroy(sp.e0);
+        (void)hipEventDestroy(sp.e1);
+    }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     delete c;
 }
@@ -883,6 +887,35 @@ int nerf_profile_read(nerf_ctx* c, double* mlp_ms, int64_t* launches, int64_t* p
         c->prof_ms = 0.0;
         c->prof_launches = 0;
         c->prof_points = 0;
+    }
+    return NERF_OK;
+}
+
+int nerf_profile_read_train(nerf_ctx* c, double* ms, int64_t* launches, int64_t* points, int reset) {
+    if (!c) return NERF_E_INVALID;
+    DeviceGuard g(c->device);
+    for (auto& sp : c->train_spans) {
+        HIP_TRY(hipEventSynchronize(sp.e1));
+        float t = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&t, sp.e0, sp.e1));
+        if (sp.kind >= 0 && sp.kind < 4) {
+            c->train_ms[sp.kind] += t;
+            c->train_launches[sp.kind] += 1;
+            c->train_points[sp.kind] += sp.points;
+        }
+        c->pool.push_back(sp.e0);
+        c->pool.push_back(sp.e1);
+    }
+    c->train_spans.clear();
+    for (int k = 0; k < 4; ++k) {
+        if (ms) ms[k] = c->train_ms[k];
+        if (launches) launches[k] = c->train_launches[k];
+        if (points) points[k] = c->train_points[k];
+        if (reset) {
+            c->train_ms[k] = 0.0;
+            c->train_launches[k] = 0;
+            c->train_points[k] = 0;
+        }
     }
     return NERF_OK;
 }

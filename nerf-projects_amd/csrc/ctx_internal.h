@@ -46,12 +46,57 @@ struct nerf_ctx {
     int64_t prof_points = 0;
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
+    // the training step's kernels while profiling is on (nerf_profile_read_train): kind 0 forward pass, 1 backward-data pass,
+    // 2 hidden-width weight gradients, 3 the other weight gradients
+    struct TrainSpan {
+        int kind;
+        hipEvent_t e0, e1;
+        int64_t points;
+    };
+    std::vector<TrainSpan> train_spans;
+    double train_ms[4] = {};
+    int64_t train_points[4] = {}, train_launches[4] = {};
 };
 
 namespace nerf {
 
 hipError_t mirror_loose(nerf_ctx* c, hipStream_t s);     // api.cpp: the precision guard's counter mirror
 unsigned take_new_loose(nerf_ctx* c);
+
+// HIP events around a stretch of a training step's launches (only while nerf_profile_enable is on)
+struct TrainTimer {
+    nerf_ctx* c;
+    hipStream_t s;
+    hipEvent_t e0 = nullptr;
+    int kind;
+    int64_t points;
+    TrainTimer(nerf_ctx* ctx, hipStream_t stream, int k, int64_t pts) : c(ctx), s(stream), kind(k), points(pts) {
+        if (!c->profiling) return;
+        if (!c->pool.empty()) {
+            e0 = c->pool.back();
+            c->pool.pop_back();
+        } else if (hipEventCreate(&e0) != hipSuccess) {
+            e0 = nullptr;
+            return;
+        }
+        (void)hipEventRecord(e0, s);
+    }
+    ~TrainTimer() {
+        if (!e0) return;
+        hipEvent_t e1 = nullptr;
+        if (!c->pool.empty()) {
+            e1 = c->pool.back();
+            c->pool.pop_back();
+        } else if (hipEventCreate(&e1) != hipSuccess) {
+            c->pool.push_back(e0);
+            return;
+        }
+        (void)hipEventRecord(e1, s);
+        c->train_spans.push_back({kind, e0, e1, points});
+    }
+    TrainTimer(const TrainTimer&) = delete;
+    TrainTimer& operator=(const TrainTimer&) = delete;
+};
 
 struct DeviceGuard {
     int prev = -1;

@@ -113,6 +113,7 @@ struct Pass {              // one network evaluated at P = N*S points with every
     float *g_a = nullptr, *g_b = nullptr, *g_hv = nullptr;   // gradient scratch
     std::vector<float*> dz;      // fused backward: d(pre-activation) of trunk layer i, [P, W]
     bool fused_backward = false;
+    nerf_ctx* ctx = nullptr;     // (for the profiling hooks)
     bool eq = false;             // the pass runs in the units of the row-equalised network (fp16-pair forward): see GradJob
     bool pair_backward = false;  // backward-data on the fp16 pipe (mlp_bwd_kernel_h2.hip); needs `eq`
     unsigned* mask[kMaxDepth] = {};   // ReLU masks of the trunk layers, one bit per unit (MlpStore::mask), and the view layer's
@@ -299,6 +300,7 @@ int forward_pass_fused(Pass& ps, const float* rays, int ray_ld, const float* z, 
         m.st.maxes = ps.maxes;
         for (int i = 0; i < a.D; ++i) m.st.mask[i] = ps.mask[i];
         m.st.mask_hv = ps.mask_hv;
+        TrainTimer timer(ps.ctx, s, 0, ps.P);
         HIP_TRY(launch_mlp_h2(m, kInputRays, s));
         return NERF_OK;
     }
@@ -306,6 +308,7 @@ int forward_pass_fused(Pass& ps, const float* rays, int ray_ld, const float* z, 
         const int rc = refresh_f32(w, s);
         if (rc != NERF_OK) return rc;
     }
+    TrainTimer timer(ps.ctx, s, 0, ps.P);
     HIP_TRY(launch_mlp(m, kInputRays, s));
     return NERF_OK;
 }
@@ -456,8 +459,10 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
         b.loose = ps.loose;
         for (int i = 0; i < a.D; ++i) b.fwd.mask[i] = ps.mask[i];
         b.fwd.mask_hv = ps.mask_hv;
+        TrainTimer timer(ps.ctx, s, 1, ps.P);
         HIP_TRY(launch_mlp_bwd_h2(b, s));
     } else {
+        TrainTimer timer(ps.ctx, s, 1, ps.P);
         HIP_TRY(launch_mlp_bwd(b, s));
     }
     // the view layer's job can join the fp16-pair batch when the feature vector's size is known: the fp16-pair forward pass
@@ -517,6 +522,7 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
         b->pts_per_slice = pps;
         b->P = ps.P;
         b->accumulate = sc.accumulate;
+        TrainTimer timer(ps.ctx, s, b == &narrow ? 3 : 2, ps.P);
         HIP_TRY(launch_grad_batch(*b, b != &narrow, sc.part, sc.part_floats, sc.dbp, sc.dbp_floats, s, b == &pairs));
     }
     return NERF_OK;
@@ -690,6 +696,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     pc.S = Sc;
     pc.fused_backward = !gemm_backward_requested() && nc.train.d_stream_bwd != nullptr && nc.out_ch == 4;
     pc.precision = precision;
+    pc.ctx = c;
     pc.loose = c->d_loose;
     set_units(pc);
     carve_pass(ar, pc);
@@ -701,6 +708,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
         pf.S = Sf;
         pf.fused_backward = !gemm_backward_requested() && nf.train.d_stream_bwd != nullptr && nf.out_ch == 4;
         pf.precision = precision;
+        pf.ctx = c;
         pf.loose = c->d_loose;
         set_units(pf);
         carve_pass(ar, pf);

@@ -107,6 +107,14 @@ class Context:
         check(self.lib.nerf_profile_read(self.handle, C.byref(ms), C.byref(n), C.byref(pts), int(reset)))
         return ms.value, n.value, pts.value
 
+    def profile_read_train(self, reset=True):
+        """{kind: (ms, launches, points)} of the training step's kernels since the last reset (while profile_enable is on):
+        forward / backward_data / weight_gradients_hidden / weight_gradients_other."""
+        ms, n, pts = (C.c_double * 4)(), (C.c_int64 * 4)(), (C.c_int64 * 4)()
+        check(self.lib.nerf_profile_read_train(self.handle, ms, n, pts, int(reset)))
+        names = ("forward", "backward_data", "weight_gradients_hidden", "weight_gradients_other")
+        return {k: (ms[i], n[i], pts[i]) for i, k in enumerate(names)}
+
     def workspace_bytes(self):
         return int(self.lib.nerf_workspace_bytes(self.handle))
 
