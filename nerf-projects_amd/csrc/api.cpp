@@ -414,7 +414,7 @@ int nerf_load_weights(nerf_ctx* c, int slot, const nerf_arch* arch, const float*
         net.n_params = total;
         // index table of the fused backward-data kernel's stream (training; view-dependent networks only)
         net.bwd_table.clear();
-        if (arch->use_viewdirs) {
+        if (arch->use_viewdirs && arch->W == kWidth) {      // (narrower networks train on the layer-by-layer chain)
             float* tsb = nullptr;
             int nbc = 0;
             rc = pack_backward_stream(*arch, fake_ptrs.data(), mask, &tsb, &nbc);

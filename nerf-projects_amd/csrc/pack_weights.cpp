@@ -155,8 +155,12 @@ int pack_backward_stream(const nerf_arch& a, const float* const* tensors, uint32
 int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors, float** stream_out,
                  int* n_chunks, float** bias_out, int* n_bias_tiles, uint32_t* skip_in_mask,
                  int* out_ch) {
-    if (a.W != kWidth) {
-        set_error("unsupported netwidth W=%d: this build specialises the MLP kernel for W=%d", a.W, kWidth);
+    // The kernels' register tiling is kWidth = 256 wide (8 accumulator tiles per layer, 4 for the view layer). A narrower
+    // network (nerf/nerf.py:9: any W) is packed into it with ZERO rows and columns for the units it does not have: their
+    // pre-activations are exactly 0, relu(0) = 0 feeds exact zeros on, and x + 0 * y = x in IEEE arithmetic - the same
+    // function bit for bit, at the 256-wide network's cost. Every column map below is bounded by the real width.
+    if (a.W < 2 || a.W > kWidth) {
+        set_error("unsupported netwidth W=%d: 2..%d (narrower networks run zero-padded to %d)", a.W, kWidth, kWidth);
         return NERF_E_INVALID;
     }
     if (a.D < 1 || a.D > kMaxDepth) {
@@ -209,6 +213,14 @@ int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors,
 
     Stream st;
     std::vector<float> bias;
+    // hidden unit f(kt, t, h) as a column of a Linear whose hidden inputs start at `off`: units >= n_units do not exist
+    // (zero padding; in the view layer they would alias the gamma(dir) columns that follow the feature vector)
+    auto hid = [](int kt, int off, int n_units) {
+        return [kt, off, n_units](int t, int h) {
+            const int c = hid_col(kt, t, h);
+            return c < n_units ? off + c : -1;
+        };
+    };
     // gamma(xyz) columns >= input_ch (multires < 10) do not exist; in a skip layer they would
     // alias the hidden columns that follow input_pts, so bound them here.
     auto xyz_col = [&](int tile) {
@@ -226,8 +238,7 @@ int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors,
         bias_tiles(bias, L, 8);
         if (i > 0) {
             const int off = pe_in ? a.input_ch : 0;
-            for (int kt = 0; kt < 8; ++kt)
-                chunk_ktile(st, L, 8, [kt, off](int t, int h) { return off + hid_col(kt, t, h); });
+            for (int kt = 0; kt < 8; ++kt) chunk_ktile(st, L, 8, hid(kt, off, a.W));
         }
         // the encoding chunks of a skip layer FOLLOW its hidden chunks: the fp16-pair kernel converts the previous
         // layer's outputs tile by tile while the hidden chunks run and has nothing left to hide behind these two
@@ -250,15 +261,14 @@ int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors,
         bias_tiles(bias, alpha, 1);
         // feature_linear (nerf.py:89): a trunk-shaped layer without ReLU
         bias_tiles(bias, feature, 8);
-        for (int kt = 0; kt < 8; ++kt)
-            chunk_ktile(st, feature, 8, [kt](int t, int h) { return hid_col(kt, t, h); });
+        for (int kt = 0; kt < 8; ++kt) chunk_ktile(st, feature, 8, hid(kt, 0, a.W));
         // alpha_linear once more as a one-row MFMA tile over the 8 k-tiles (group = kt*4 + t4), for the fp16-pair
         // kernel, whose vector pipe is busy converting activations; the fp32 kernel passes over this chunk
         {
             float* c = st.new_chunk();
             for (int kt = 0; kt < 8; ++kt)
                 for (int t4 = 0; t4 < 4; ++t4)
-                    fill_group(c, kt * 4 + t4, alpha, 0, t4, [kt](int t, int h) { return hid_col(kt, t, h); });
+                    fill_group(c, kt * 4 + t4, alpha, 0, t4, hid(kt, 0, a.W));
         }
         // views_linears.0 (nerf.py:93-98): input cat[feature(W), gamma(dir)], 4 output tiles.
         // two feature k-tiles per chunk: group = (ktl*4 + ot)*4 + t4
@@ -269,8 +279,7 @@ int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors,
                 for (int ot = 0; ot < 4; ++ot)
                     for (int t4 = 0; t4 < 4; ++t4) {
                         const int kt = 2 * kp + ktl;
-                        fill_group(c, (ktl * 4 + ot) * 4 + t4, views, ot, t4,
-                                   [kt](int t, int h) { return hid_col(kt, t, h); });
+                        fill_group(c, (ktl * 4 + ot) * 4 + t4, views, ot, t4, hid(kt, 0, a.W));
                     }
         }
         {
@@ -290,7 +299,7 @@ int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors,
         float* c = st.new_chunk();
         for (int kt = 0; kt < 8; ++kt)
             for (int t4 = 0; t4 < 4; ++t4)
-                fill_group(c, kt * 4 + t4, outl, 0, t4, [kt](int t, int h) { return hid_col(kt, t, h); });
+                fill_group(c, kt * 4 + t4, outl, 0, t4, hid(kt, 0, a.W));
         bias_tiles(bias, outl, 1);
         *out_ch = a.output_ch;
     }

@@ -43,7 +43,7 @@ bool gemm_forward_requested();
 // stream (refresh_h2), the backward-data streams (refresh_bwd). Only the layer-by-layer forward GEMMs' W^T copies are
 // made here.
 int mark_params_changed(PackedNet& net, hipStream_t s, bool stepped) {
-    if (gemm_forward_requested())      // W^T is the B operand of the layer-by-layer forward GEMMs only
+    if (gemm_forward_requested() || net.arch.W != kWidth)      // W^T is the B operand of the layer-by-layer forward GEMMs only
         for (const LinearDesc& d : net.linears)
             HIP_TRY(launch_transpose(net.d_params + d.w_off, d.out, d.in, net.train.d_wt + d.w_off, s));
     if (stepped) {
@@ -316,7 +316,9 @@ int forward_pass_fused(Pass& ps, const float* rays, int ray_ld, const float* z, 
 int forward_pass(Pass& ps, const float* rays, int ray_ld, const float* z, hipStream_t s) {
     const PackedNet& net = *ps.net;
     const nerf_arch& a = net.arch;
-    if (!gemm_forward_requested() && ps.C == net.out_ch && a.D <= kMaxDepth) return forward_pass_fused(ps, rays, ray_ld, z, s);
+    // (the fused kernels keep 256-wide rows: a narrower network, which they evaluate zero-padded, trains on the chain below)
+    if (!gemm_forward_requested() && ps.C == net.out_ch && a.D <= kMaxDepth && a.W == kWidth)
+        return forward_pass_fused(ps, rays, ray_ld, z, s);
     const float* wt = net.train.d_wt;
     const float* prm = net.d_params;
     const int Lx = (a.input_ch - 3) / 6, Lv = a.use_viewdirs ? (a.input_ch_views - 3) / 6 : 0;
@@ -591,7 +593,7 @@ int backward_pass(Pass& ps, const TnScratch& sc, hipStream_t s) {
 // are brought back to the plain parameters' by exact powers of two where their slices are added up (GradJob::ex).
 void set_units(Pass& ps) {
     const nerf_arch& a = ps.net->arch;
-    const bool fused_forward = !gemm_forward_requested() && a.D <= kMaxDepth;
+    const bool fused_forward = !gemm_forward_requested() && a.D <= kMaxDepth && a.W == kWidth;
     ps.eq = ps.precision == NERF_PRECISION_F16X2 && pair_forward_allowed() && fused_forward && a.use_viewdirs &&
             (uint64_t)ps.P * (uint64_t)(a.W + a.input_ch + 4) * 4u < ((uint64_t)1 << 32);
     ps.pair_backward = ps.eq && ps.fused_backward && pair_bwd_allowed();

@@ -559,6 +559,50 @@ def gold_train_variants():
     save("train_step_variants", rays=n(rays), target=n(target), **out)
 
 
+def gold_widths():
+    """Networks narrower than 256 (nerf/nerf.py:9: any W; all 18 shipped YAMLs use 256): NeRF.forward for W = 128, 64 and an
+    odd 100 (views_linears is W // 2 wide), render_rays at 64+128 with a W = 128 pair incl. the reference's fp64 render of the
+    same rays, and one training iteration of the W = 128 pair (losses, gradient norms and every 61st element)."""
+    rs = np.random.RandomState(131)
+    x, d, emb = encoded_batch(rs, 256)
+    out = dict(embedded=n(emb))
+    with torch.no_grad():
+        for tag, seed, arch in (("w128", 41, dict(W=128)), ("w64", 42, dict(W=64)),
+                                ("w100_noview5", 43, dict(W=100, use_viewdirs=False, output_ch=5)),
+                                ("w128_d4", 45, dict(W=128, D=4, skips=(1,)))):
+            out["out_" + tag] = n(ref_model(seed, **arch)(emb))
+            out["out_" + tag + "_fp64"] = n(ref_model(seed, dtype=torch.float64, **arch)(emb.double()))
+            out["digest_" + tag] = synthetic.state_dict_digest(synthetic.synthetic_state_dict(seed, **arch))
+    g = np.load(os.path.join(HERE, "render_rays_lego.npz"))
+    rays = g["rays"][:64]
+    kw = dict(N_samples=64, N_importance=128, retraw=True, white_bkgd=True, perturb=0., raw_noise_std=0.)
+    net_c, net_f = ref_model(41, W=128), ref_model(44, W=128)
+    ret, rec = capture_render_rays(rays, net_c, net_f, **kw)
+    ret64, _ = capture_render_rays(rays, ref_model(41, dtype=torch.float64, W=128), ref_model(44, dtype=torch.float64, W=128),
+                                   dtype=torch.float64, **kw)
+    out.update({"rr_" + k: v for k, v in ret.items()})
+    out.update({"rr_" + k + "_fp64": v.astype(np.float64) for k, v in ret64.items() if k != "raw"})
+    out.update(rr_rays=rays, rr_z_coarse=rec["r2o"][0]["z_vals"], rr_z_samples=rec["pdf"][0], rr_z_fine=rec["r2o"][1]["z_vals"])
+    # one training iteration (nerf.ipynb:1258-1275) with the reference's pytest RNG
+    rays_t = torch.from_numpy(g["rays"][:32])
+    target = torch.from_numpy(np.random.RandomState(106).uniform(0, 1, size=(32, 3)).astype(np.float32))
+    net_c, net_f = ref_model(41, W=128), ref_model(44, W=128)
+    net_c.train(); net_f.train()
+    e_fn, _ = ref_embedder.get_embedder(10, 0)
+    ed_fn, _ = ref_embedder.get_embedder(4, 0)
+    kwt = dict(N_samples=64, N_importance=128, retraw=True, white_bkgd=True, perturb=1.0, raw_noise_std=1.0, pytest=True)
+    r = NS["render_rays"](rays_t, net_c, query_fn(e_fn, ed_fn), network_fine=net_f, **kwt)
+    img_loss, img_loss0 = ref_helpers.img2mse(r["rgb_map"], target), ref_helpers.img2mse(r["rgb0"], target)
+    (img_loss + img_loss0).backward()
+    out.update(tr_target=n(target), tr_img_loss=n(img_loss), tr_img_loss0=n(img_loss0))
+    for tag, net in (("c", net_c), ("f", net_f)):
+        for k, p in net.named_parameters():
+            gr = n(p.grad).reshape(-1) if p.grad is not None else np.zeros(p.numel(), np.float32)
+            out[f"tr_gnorm_{tag}.{k}"] = np.linalg.norm(gr.astype(np.float64))
+            out[f"tr_gsub_{tag}.{k}"] = gr[::61].copy()
+    save("widths", **out)
+
+
 def gold_llff_pose_math():
     """The pure-numpy pose functions of nerf/load_llff.py, executed from its source (the module itself
     cannot be imported here: it needs imageio). Only function definitions that touch numpy alone are
@@ -701,5 +745,6 @@ if __name__ == "__main__":
     gold_train()
     gold_train_variants()
     gold_train_adam_state()
+    gold_widths()
     gold_llff_pose_math()
     gold_tiny_scene()

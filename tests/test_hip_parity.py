@@ -478,6 +478,75 @@ def test_mlp_forward(N):
     assert net(x[:0]).shape == (0, 4)
 
 
+WIDTHS = (("w128", 41, dict(W=128)), ("w64", 42, dict(W=64)), ("w100_noview5", 43, dict(W=100, use_viewdirs=False, output_ch=5)),
+          ("w128_d4", 45, dict(W=128, D=4, skips=(1,))))
+
+
+def test_network_widths_other_than_256(N):
+    """NeRF(W=...) for W = 128, 64 and an odd 100 (nerf/nerf.py:9, :32-55: any width; views_linears is W // 2 wide): the
+    packer zero-pads them into the kernels' 256-wide tiling - exactly the same function - and the outputs match the
+    reference's own fp32 / fp64 evaluation like the 256-wide ones do (tests/golden/widths.npz)."""
+    g = load_golden("widths")
+    x = gpu(g["embedded"])
+    for tag, seed, arch in WIDTHS:
+        sd = synthetic.synthetic_state_dict(seed, **arch)
+        assert synthetic.state_dict_digest(sd) == str(g["digest_" + tag])
+        net = make_net(N, sd, **{k: (list(v) if k == "skips" else v) for k, v in arch.items()})
+        out, want, want64 = cpu(net(x)), g["out_" + tag], g["out_" + tag + "_fp64"]
+        scale = max(1.0, np.abs(want).max())
+        assert out.shape == want.shape
+        assert np.abs(out - want).max() <= 3e-6 * scale, tag                          # vs reference fp32
+        assert np.abs(out - want64).max() <= 4 * np.abs(want - want64).max() + 1e-6, tag      # vs reference fp64
+        assert np.abs(cpu(net(x[:77])) - want[:77]).max() <= 3e-6 * scale
+
+
+def test_render_rays_width_128(N):
+    """render_rays at 64+128 with a W = 128 coarse / fine pair against the reference's own render of the same rays, by the
+    reference-anchored criterion (fine pass at the reference's depths, flips against its fp32-vs-fp64 count)."""
+    g = load_golden("widths")
+    net_c = make_net(N, synthetic.synthetic_state_dict(41, W=128), W=128)
+    net_f = make_net(N, synthetic.synthetic_state_dict(44, W=128), W=128)
+    q = N.make_network_query_fn(N.get_embedder(10, 0)[0], N.get_embedder(4, 0)[0])
+    kw = dict(N_samples=64, N_importance=128, network_fine=net_f, white_bkgd=True)
+    rays = gpu(g["rr_rays"])
+    ret = N.render_rays(rays, net_c, q, retraw=True, **kw)
+    want = {k[3:]: g[k] for k in g.files if k.startswith("rr_")}
+    for k in ("rgb0", "acc0"):
+        assert np.abs(cpu(ret[k]) - want[k]).max() <= 1e-5, k
+    inj = N.render_rays(rays, net_c, q, _z_vals_fine=want["z_fine"], **kw)
+    assert np.abs(cpu(N.render_rays(rays, net_c, q, retraw=True, _z_vals_fine=want["z_fine"], **kw)["raw"]) - want["raw"]).max() \
+        <= 5e-6 * max(1.0, np.abs(want["raw"]).max())
+    check_resampled(npd(ret), want, injected=npd(inj), fp64=want)
+
+
+def test_train_step_width_128(N):
+    """One training iteration of a W = 128 pair against the reference's autograd (the narrow networks train on the
+    layer-by-layer chain): both losses and every gradient tensor, bars of test_train_gradients_match_autograd."""
+    g = load_golden("widths")
+    net_c = make_net(N, synthetic.synthetic_state_dict(41, W=128), W=128)
+    net_f = make_net(N, synthetic.synthetic_state_dict(44, W=128), W=128)
+    rays = load_golden("train_step")["rays"]
+    kw = dict(network_fn=net_c, network_fine=net_f, N_samples=64, N_importance=128, white_bkgd=True, perturb=1.0,
+              raw_noise_std=1.0, pytest=True, ndc=False, use_viewdirs=True, near=2., far=6.)
+    opt = N.Adam([net_c, net_f], lr=5e-4)
+    out = N.train_on_batch(800, 800, None, (gpu(rays[:, 0:3]), gpu(rays[:, 3:6])), gpu(g["tr_target"]), opt,
+                           apply_update=False, **kw)
+    assert abs(float(out["img_loss"]) - float(g["tr_img_loss"])) <= 2e-6
+    assert abs(float(out["img_loss0"]) - float(g["tr_img_loss0"])) <= 2e-6
+    for tag, net in (("c", net_c), ("f", net_f)):
+        for k, gr in net.grad_dict().items():
+            gr = gr.numpy().reshape(-1)
+            want_norm, want_sub = float(g[f"tr_gnorm_{tag}.{k}"]), g[f"tr_gsub_{tag}.{k}"]
+            tol = 2e-5 if tag == "c" else 2e-4
+            assert abs(np.linalg.norm(gr.astype(np.float64)) - want_norm) <= tol * want_norm + 1e-9, (tag, k)
+            assert np.abs(gr[::61] - want_sub).max() <= 5 * tol * (np.abs(want_sub).max() + 1e-12) + 1e-9, (tag, k)
+    # ... and an optimiser step moves what both kernels render
+    x = gpu(g["embedded"])
+    before = cpu(net_c(x))
+    N.train_on_batch(800, 800, None, (gpu(rays[:, 0:3]), gpu(rays[:, 3:6])), gpu(g["tr_target"]), opt, **kw)
+    assert np.abs(cpu(net_c(x)) - before).max() > 1e-6
+
+
 def test_run_network_fused_matches_staged(N, O):
     """Fused encode+MLP == embed kernel -> cat -> MLP kernel, and both == oracle."""
     g = load_golden("mlp_forward")
@@ -867,9 +936,9 @@ def test_c1_full_frame_coarse_only(N, O, nets):
 
 def test_errors_are_exceptions(N, nets):
     net_c, net_f, q = nets
-    with pytest.raises(RuntimeError):
-        N.NeRF(D=8, W=128, input_ch=63, input_ch_views=27, use_viewdirs=True).load_state_dict(
-            synthetic.synthetic_state_dict(3, W=128))                    # unsupported width: loud, not silent
+    with pytest.raises(RuntimeError, match="netwidth"):
+        N.NeRF(D=8, W=320, input_ch=63, input_ch_views=27, use_viewdirs=True).load_state_dict(
+            synthetic.synthetic_state_dict(3, W=320))                    # wider than the register tiling: loud, not silent
     with pytest.raises(RuntimeError):
         make_net(N, {k: v for k, v in synthetic.synthetic_state_dict(7).items() if "alpha" not in k})
     with pytest.raises(RuntimeError):

@@ -288,3 +288,28 @@ def test_gemm_backends_agree(weights_pair):
     assert np.abs(a - b).max() <= 3e-6 * scale and np.abs(b - g["out"]).max() <= 3e-6 * scale
     with pytest.raises(ValueError):
         O.set_gemm_backend("cupy")
+
+
+def test_network_widths_other_than_256():
+    """The oracle on the reference's W = 128 / 64 / 100 networks (tests/golden/widths.npz): NeRF.forward, and render_rays
+    with a W = 128 pair by the reference-anchored criterion."""
+    from nerf_projects_amd import synthetic
+    g = load_golden("widths")
+    for tag, seed, arch in (("w128", 41, dict(W=128)), ("w64", 42, dict(W=64)),
+                            ("w100_noview5", 43, dict(W=100, use_viewdirs=False, output_ch=5)),
+                            ("w128_d4", 45, dict(W=128, D=4, skips=(1,)))):
+        sd = synthetic.synthetic_state_dict(seed, **arch)
+        assert synthetic.state_dict_digest(sd) == str(g["digest_" + tag])
+        net = O.NeRF(arch.get("D", 8), arch["W"], 63, 27, arch.get("output_ch", 4), arch.get("skips", (4,)),
+                     arch.get("use_viewdirs", True), sd)
+        want = g["out_" + tag]
+        assert np.abs(net(g["embedded"]) - want).max() <= 3e-6 * max(1.0, np.abs(want).max()), tag
+    net_c = O.NeRF(8, 128, 63, 27, 4, (4,), True, synthetic.synthetic_state_dict(41, W=128))
+    net_f = O.NeRF(8, 128, 63, 27, 4, (4,), True, synthetic.synthetic_state_dict(44, W=128))
+    q = O.make_query_fn(O.get_embedder(10)[0], O.get_embedder(4)[0])
+    want = {k[3:]: g[k] for k in g.files if k.startswith("rr_")}
+    kw = dict(N_samples=64, N_importance=128, network_fine=net_f, white_bkgd=True)
+    ret = O.render_rays(want["rays"], net_c, q, **kw)
+    inj = O.render_rays(want["rays"], net_c, q, _inject={"z_fine": want["z_fine"]}, **kw)
+    assert np.abs(ret["rgb0"] - want["rgb0"]).max() <= 5e-6
+    check_resampled(ret, want, injected=inj, fp64=want)

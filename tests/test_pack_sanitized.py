@@ -37,6 +37,15 @@ def hidden_col(tile, t, h):
     return 32 * tile + (t & 3) + 8 * (t >> 2) + 4 * h
 
 
+def hid(kt, off, n_units):
+    """Hidden unit f(kt, t, h) as a column of a Linear whose hidden inputs start at `off`; units the network does not have
+    (W < 256: zero padding) map to no column."""
+    def col(t, h):
+        c = hidden_col(kt, t, h)
+        return off + c if c < n_units else -1
+    return col
+
+
 def pe_col_xyz(s, h):
     """Column of gamma(xyz) held by slot s = 16 tile + t of half-wave h (sines in h = 0, cosines in h = 1; slots 0..14 the
     five frequencies the half-wave evaluates, 15..29 its partner's, 30 / 31 the raw coordinates), -1 for padding."""
@@ -105,12 +114,12 @@ def chunk_ktile(L, n_ot, col):
     return c
 
 
-def chunk_row(L, n_kt=8):
+def chunk_row(L, W, n_kt=8):
     c = np.zeros(CHUNK)
     for kt in range(n_kt):
         for t4 in range(4):
             gi = kt * 4 + t4
-            c[gi * 256:(gi + 1) * 256] = group(L, 0, t4, lambda t, h, kt=kt: hidden_col(kt, t, h))
+            c[gi * 256:(gi + 1) * 256] = group(L, 0, t4, hid(kt, 0, W))
     return c
 
 
@@ -148,7 +157,7 @@ def repack(D, W, in_ch, in_v, out_ch, viewdirs, skips):
         if i > 0:
             off = in_ch if pe_in else 0
             for kt in range(8):
-                stream.append(chunk_ktile(L, 8, lambda t, h, kt=kt, off=off: off + hidden_col(kt, t, h)))
+                stream.append(chunk_ktile(L, 8, hid(kt, off, W)))
                 ids.append(i)
         if pe_in:
             stream += [chunk_ktile(L, 8, xyz_col(0)), chunk_ktile(L, 8, xyz_col(1))]
@@ -160,9 +169,9 @@ def repack(D, W, in_ch, in_v, out_ch, viewdirs, skips):
         rgb = Lin(3, W // 2, alpha.next)
         bias += bias_tiles(alpha, 1) + bias_tiles(feature, 8)
         for kt in range(8):
-            stream.append(chunk_ktile(feature, 8, lambda t, h, kt=kt: hidden_col(kt, t, h)))
+            stream.append(chunk_ktile(feature, 8, hid(kt, 0, W)))
             ids.append(D)
-        stream.append(chunk_row(alpha))
+        stream.append(chunk_row(alpha, W))
         ids.append(D + 2)
         bias += bias_tiles(views, 4)
         for kp in range(4):
@@ -171,8 +180,7 @@ def repack(D, W, in_ch, in_v, out_ch, viewdirs, skips):
                 for ot in range(4):
                     for t4 in range(4):
                         gi = (ktl * 4 + ot) * 4 + t4
-                        c[gi * 256:(gi + 1) * 256] = group(views, ot, t4,
-                                                           lambda t, h, kt=2 * kp + ktl: hidden_col(kt, t, h))
+                        c[gi * 256:(gi + 1) * 256] = group(views, ot, t4, hid(2 * kp + ktl, 0, W))
             stream.append(c)
             ids.append(D + 1)
 
@@ -185,8 +193,15 @@ def repack(D, W, in_ch, in_v, out_ch, viewdirs, skips):
         for c in range(3):
             bias += row_tiles(rgb, c, 4)
         n_out = 4
+    else:
+        outl = Lin(out_ch, W, first)
+        stream.append(chunk_row(outl, W))
+        ids.append(D)
+        bias += bias_tiles(outl, 1)
+        n_out = out_ch
+    if viewdirs and W == 256:
         # backward stream: W_views[:, :W]^T (4 k-tiles), W_feature^T, the alpha column, W_i[:, hidden]^T for i = D-1..1
-        def layer_t(T, n_kt):
+        def layer_t(T, n_kt):  # noqa: E306
             for kt in range(n_kt):
                 bwd.append(chunk_ktile(T, 8, lambda t, h, kt=kt: hidden_col(kt, t, h)))
         layer_t(LinT(views, W, W // 2, 0), 4)
@@ -199,19 +214,17 @@ def repack(D, W, in_ch, in_v, out_ch, viewdirs, skips):
         bwd.append(chunk_ktile(AlphaColumn, 8, lambda t, h: hidden_col(0, t, h)))
         for i in range(D - 1, 0, -1):
             layer_t(LinT(lins[i], W, W, in_ch if (mask >> i) & 1 else 0), 8)
-    else:
-        outl = Lin(out_ch, W, first)
-        stream.append(chunk_row(outl))
-        ids.append(D)
-        bias += bias_tiles(outl, 1)
-        n_out = out_ch
     return (np.concatenate(stream).astype(np.float32), np.asarray(bias, np.float32),
             np.concatenate(bwd).astype(np.float32) if bwd else np.zeros(0, np.float32), np.asarray(ids, np.int32), mask, n_out)
 
 
 VARIANTS = [
-    # D, input_ch, input_ch_views, output_ch, use_viewdirs, skips
+    # D, input_ch, input_ch_views, output_ch, use_viewdirs, skips[, W]
     (8, 63, 27, 4, 1, (4,)),            # the reference's 18 YAMLs
+    (8, 63, 27, 4, 1, (4,), 128),       # narrower networks: zero-padded into the 256-wide tiling
+    (8, 63, 0, 5, 0, (4,), 100),        # (views_linears is W // 2 = 50 wide)
+    (4, 63, 27, 4, 1, (1,), 64),
+    (3, 21, 9, 4, 1, (), 2),
     (8, 63, 27, 5, 1, (4,)),
     (8, 63, 0, 5, 0, (4,)),             # use_viewdirs=False, N_importance > 0 (nerf.ipynb:885)
     (8, 63, 0, 4, 0, (4,)),
@@ -229,10 +242,11 @@ VARIANTS = [
 ]
 
 
-@pytest.mark.parametrize("D,in_ch,in_v,out_ch,viewdirs,skips", VARIANTS)
-def test_packer_is_clean_and_matches_the_layout(driver, tmp_path, D, in_ch, in_v, out_ch, viewdirs, skips):
+@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: "D%d_in%d_%d_out%d_vd%d_skips%s_W%d" % (v[:5] + ("-".join(map(str, v[5])), (v + (256,))[6])))
+def test_packer_is_clean_and_matches_the_layout(driver, tmp_path, variant):
+    D, in_ch, in_v, out_ch, viewdirs, skips, W = (variant + (256,))[:7]
     out = tmp_path / "dump.bin"
-    cmd = [driver, str(D), "256", str(in_ch), str(in_v), str(out_ch), str(viewdirs), str(len(skips))] + [str(s) for s in skips] + [str(out)]
+    cmd = [driver, str(D), str(W), str(in_ch), str(in_v), str(out_ch), str(viewdirs), str(len(skips))] + [str(s) for s in skips] + [str(out)]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
@@ -245,7 +259,7 @@ def test_packer_is_clean_and_matches_the_layout(driver, tmp_path, D, in_ch, in_v
     bwd, body = body[:n_bwd * CHUNK], body[n_bwd * CHUNK:]
     ids = body.view(np.int32)
     assert len(ids) == n_ids == n_chunks
-    w_stream, w_bias, w_bwd, w_ids, w_mask, w_out = repack(D, 256, in_ch, in_v, out_ch, viewdirs, skips)
+    w_stream, w_bias, w_bwd, w_ids, w_mask, w_out = repack(D, W, in_ch, in_v, out_ch, viewdirs, skips)
     assert mask == w_mask and n_out == w_out
     assert np.array_equal(ids, w_ids)
     assert stream.shape == w_stream.shape and np.array_equal(stream, w_stream)
@@ -261,7 +275,8 @@ def test_packer_is_clean_and_matches_the_layout(driver, tmp_path, D, in_ch, in_v
 
 
 @pytest.mark.parametrize("args", [
-    ["8", "128", "63", "27", "4", "1", "1", "4"],        # W != 256 is refused with a message, not packed out of bounds
+    ["8", "320", "63", "27", "4", "1", "1", "4"],        # wider than the 256-wide register tiling: refused with a message
+    ["8", "1", "63", "27", "4", "1", "0"],               # W // 2 = 0 view units
     ["13", "256", "63", "27", "4", "1", "0"],            # D > 12
     ["8", "256", "64", "27", "4", "1", "0"],             # input_ch not 3 + 6 L
     ["8", "256", "63", "27", "4", "1", "1", "7"],        # skip at the last trunk layer
