@@ -374,7 +374,7 @@ hipError_t launch_grad_batch(GradBatch& b, bool wide, float* part, size_t part_f
         g.part = part + used;
         g.dbp = dbp + used_db;
         used += (size_t)b.n_slices * g.Mo * width;
-        used_db += (size_t)b.n_slices * g.Mo;
+        if (g.db) used_db += (size_t)b.n_slices * g.Mo;      // (only the job that owns the bias gradient writes bias partials)
         const int64_t th = ((int64_t)g.Mo * width + 3) / 4 + g.Mo;
         max_threads = th > max_threads ? th : max_threads;
     }
