@@ -229,16 +229,26 @@ __device__ __forceinline__ float row_dot(const f32x16 (&x)[8], const float* bias
     return s + __shfl_xor(s, 32);
 }
 
+// Returns the largest activation (its magnitude without ReLU) of this lane: +inf means the layer overflowed fp32 here,
+// which poisons what follows in the reference - F.relu keeps +inf and NaN (nerf.py:72) and the next Linear mixes inf - inf -
+// while v_max_f32 drops the NaNs that mix produces. One v_max3 per register pair (a compare per value into a scalar mask cost
+// this kernel 4 %).
 template <int N, bool RELU>
-__device__ __forceinline__ void activate(f32x16 (&dst)[8], const f32x16 (&src)[8]) {
+__device__ __forceinline__ float activate(f32x16 (&dst)[8], const f32x16 (&src)[8]) {
+    float top = 0.0f;
 #pragma unroll
     for (int t = 0; t < N; ++t)
 #pragma unroll
 #ifdef NERF_ABLATE_RELU
         for (int r = 0; r < 16; ++r) dst[t][r] = (r == 0 && t == 0) ? src[t][r] : dst[t][r];
 #else
-        for (int r = 0; r < 16; ++r) dst[t][r] = RELU ? fmaxf(src[t][r], 0.0f) : src[t][r];
+        for (int r = 0; r < 16; r += 2) {
+            dst[t][r] = RELU ? fmaxf(src[t][r], 0.0f) : src[t][r];
+            dst[t][r + 1] = RELU ? fmaxf(src[t][r + 1], 0.0f) : src[t][r + 1];
+            top = fmaxf(fmaxf(top, fabsf(dst[t][r])), fabsf(dst[t][r + 1]));
+        }
 #endif
+    return top;
 }
 
 // Training forward (STORE): N activation tiles of this wave's 32 points to a row-major [points, channels] buffer. A lane
@@ -358,7 +368,7 @@ void nerf_mlp_kernel(const MlpLaunch a) {
     load_bias<8>(acc, bias_lds, 0, h);
     chunk_ktile8(pipe, cur, acc, x0);
     chunk_ktile8(pipe, cur, acc, x1);
-    activate<8, true>(hid, acc);
+    float top = activate<8, true>(hid, acc);      // +inf: an fp32 overflow somewhere in the trunk, in this lane's half of the point
 
     // trunk layers 1..D-1, then (with viewdirs) feature_linear as layer D without ReLU
     const int n_layers = a.use_viewdirs ? a.D + 1 : a.D;
@@ -369,6 +379,7 @@ void nerf_mlp_kernel(const MlpLaunch a) {
             // alpha_linear reads the post-ReLU trunk output before feature_linear (nerf.py:86-89): one output
             // row, evaluated as a dot product over the 128 activations this lane holds + the other half-wave's
             sigma = row_dot<8>(hid, bias_lds, 8 * a.D + 14, h) + bias_lds[(8 * a.D) * 32];
+            if (!(fmaxf(top, __shfl_xor(top, 32)) < __builtin_inff())) sigma = __builtin_nanf("");      // (either half of the point)
         }
         load_bias<8>(acc, bias_lds, is_feature ? 8 * a.D + 1 : 8 * i, h);
         // (training: tile kt of the previous layer's output - this chunk's B operand - goes to memory behind this chunk's
@@ -390,9 +401,9 @@ void nerf_mlp_kernel(const MlpLaunch a) {
             // the stream carries alpha_linear as an MFMA tile here for the fp16-pair kernel; this kernel has it from
             // row_dot above and only keeps the ring turning
             consume_chunk<8>(pipe, cur, [&](auto, auto, const Frag16&) {});
-            activate<8, false>(hid, acc);
+            top = fmaxf(top, activate<8, false>(hid, acc));
         } else {
-            activate<8, true>(hid, acc);
+            top = fmaxf(top, activate<8, true>(hid, acc));
         }
     }
     // without a view layer the last trunk output has no following chunks to ride behind
@@ -404,6 +415,7 @@ void nerf_mlp_kernel(const MlpLaunch a) {
         f32x16 t0, t1, t2;
         load_inputs<MODE, false, false>(a, pt, h, t0, t1, t2, nullptr, &bad);
     }
+    const bool poisoned = !(fmaxf(top, __shfl_xor(top, 32)) < __builtin_inff());      // both halves of the point
     if (a.use_viewdirs) {
         // views_linears[0] on cat[feature, gamma(dir)] (nerf.py:93-98): 4 output tiles
         load_bias<4>(acc, bias_lds, 8 * a.D + 9, h);
@@ -429,7 +441,7 @@ void nerf_mlp_kernel(const MlpLaunch a) {
         if (live && h == 0) {
             // outputs = cat[rgb, alpha] (nerf.py:106)
             f32x4 o = {r0, r1, r2, sigma};
-            if (bad) {
+            if (bad || poisoned) {      // (poisoned: the trunk or feature_linear overflowed; sigma has its own mark above)
                 const float qnan = __builtin_nanf("");
                 o = f32x4{qnan, qnan, qnan, (bad & kBadXyz) ? qnan : sigma};
             }
@@ -443,7 +455,7 @@ void nerf_mlp_kernel(const MlpLaunch a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < a.out_ch) a.out[pt * a.out_ch + row] = (bad & kBadXyz) ? __builtin_nanf("") : o[r];
+                if (row < a.out_ch) a.out[pt * a.out_ch + row] = ((bad & kBadXyz) || poisoned) ? __builtin_nanf("") : o[r];
             }
         }
     }

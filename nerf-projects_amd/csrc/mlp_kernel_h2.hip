@@ -403,7 +403,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
         f32x16 accA[8], accB[8];
         Pending pd;
         float sigma = 0.0f;
-        float m_prev;    // largest |activation| of the layer before the pending one... of its inputs
+        float m_prev = 0.0f;    // largest |activation| of the layer before the pending one... of its inputs
 
         // what the raw sums of layer l become: called when its chunks are done. m_in = largest |input| of layer l
         // (true units), t_in = exponent its inputs were scaled by
@@ -436,7 +436,12 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             pd.t_out = pick_exponent(bound);
             pd.sc = pow2f(pd.t_out);
             pd.bias_addr = baddr;
-            pd.m = 0.0f;
+            // The running maximum starts at 0 - or at +inf when the layer before had overflowed ON THIS POINT (m_prev = inf; not
+            // m_in, which takes in the wave-wide range of the encodings): an activation beyond the fp32 range poisons
+            // everything downstream in the reference (F.relu keeps +inf and NaN, nerf.py:72; the next Linear mixes
+            // inf - inf), v_max_f32 would quietly drop the NaNs, and carrying the fact in the maximum costs no register:
+            // the heads below turn m = inf into the reference's NaN.
+            pd.m = fmaxf(m_prev - 3.4028234663852886e38f, 0.0f);
             if constexpr (STORE) {
                 pd.maskw = 0u;
                 pd.mask_base = wave_uniform(is_feature ? a.st.mask_hv : a.st.mask[l]);      // (feature_linear: not written)
@@ -468,7 +473,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             // the scale was chosen for a bound of 2^(10 - t_out); outputs 2^12 and more below it have begun to lose
             // low-half bits (see Pending). Counted, never silent: nerf_precision_status.
             const int slack = 10 - pd.t_out - __builtin_amdgcn_frexp_expf(m_prev);
-            if (m_prev > 0.0f && slack >= 12 && pd.t_out > -60 && a.loose) atomicAdd(a.loose, 1u);
+            if (m_prev > 0.0f && m_prev < __builtin_inff() && slack >= 12 && pd.t_out > -60 && a.loose) atomicAdd(a.loose, 1u);
         };
 
         // layer 0: gamma(xyz) -> W (nerf.py:70-73)
@@ -496,6 +501,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
                 // chunk, a single-row tile accumulated into a pending tile that is no longer needed
                 chunk_row8(pipe, cur, pend[0], hid);
                 sigma = fmaf(pend[0][0], lds_scalar(layer_tab + 4 * (a.D + 2)) * pow2f(-t_in), lds_scalar(bias_lds + (8 * a.D) * 32));
+                if (!(m_prev < __builtin_inff())) sigma = __builtin_nanf("");      // the trunk overflowed on this point (make_pending)
             }
             if (!(a.use_viewdirs && l == a.D) && ((a.skip_in_mask >> l) & 1)) {
                 // h = cat[input_pts, h] (nerf.py:79-80): bring the encoded inputs to this layer's scale
@@ -535,6 +541,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             chunk_pair4<6, false, STORE>(pipe, cur, accB, hid[4], hid[5], hid, accA, pd);
             chunk_pair4<-1, false>(pipe, cur, accB, hid[6], hid[7], hid, accA, pd);
             close_pending(kBwdMaxFeatValue);
+            const bool rgb_poisoned = !(m_prev < __builtin_inff());      // the trunk or feature_linear overflowed (make_pending)
             XT xd;
             {
                 f32x16 x0, x1, dd;
@@ -564,7 +571,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             const float r2 = row_dot4(y, bias0 + 128 * (8 * a.D + 30)) + lds_scalar(rb + 2);
             if (live && h == 0) {
                 f32x4 o = {r0, r1, r2, sigma};   // outputs = cat[rgb, alpha] (nerf.py:106)
-                if (bad) {                       // NaN / Inf inputs propagate as through F.relu (see kBadXyz)
+                if (bad || rgb_poisoned) {       // NaN / Inf inputs propagate as through F.relu (see kBadXyz)
                     const float qnan = __builtin_nanf("");
                     o = f32x4{qnan, qnan, qnan, (bad & kBadXyz) ? qnan : sigma};
                 }
@@ -580,6 +587,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             convert_tile<5>(hid[5], accA[5], pd);
             convert_tile<6>(hid[6], accA[6], pd);
             convert_tile<7>(hid[7], accA[7], pd);
+            const bool poisoned = !(half_max(pd.m) < __builtin_inff());      // the trunk overflowed on this point (make_pending)
             f32x16 o;
             chunk_row8(pipe, cur, o, hid);
             Tile16 b = lds_tile_issue(bias0 + 128 * (8 * a.D));
@@ -595,7 +603,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (row < a.out_ch)
-                        a.out[pt * a.out_ch + row] = (bad & kBadXyz) ? __builtin_nanf("") : fmaf(o[r], c, b.q[r >> 2][r & 3]);
+                        a.out[pt * a.out_ch + row] = ((bad & kBadXyz) || poisoned) ? __builtin_nanf("") : fmaf(o[r], c, b.q[r >> 2][r & 3]);
                 }
             }
         }

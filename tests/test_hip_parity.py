@@ -152,10 +152,11 @@ def test_embed(N):
     assert e(gpu(g["x"]).reshape(8, 8, 3)).shape == (8, 8, 63)
 
 
-def _forward_fp64(sd, x, D, skips, use_viewdirs, input_ch=63):
-    """NeRF.forward (nerf/nerf.py:57-111) in float64 on the CPU: the yardstick both kernels are measured against."""
-    g = lambda k: torch.as_tensor(np.asarray(sd[k]), dtype=torch.float64)
-    x = x.double().cpu()
+def _forward_fp64(sd, x, D, skips, use_viewdirs, input_ch=63, dtype=torch.float64):
+    """NeRF.forward (nerf/nerf.py:57-111) in float64 on the CPU: the yardstick both kernels are measured against
+    (dtype=torch.float32: the same operations as the reference runs them, NaN / Inf behaviour included)."""
+    g = lambda k: torch.as_tensor(np.asarray(sd[k]), dtype=dtype)
+    x = x.to(dtype).cpu()
     pts, views = x[:, :input_ch], x[:, input_ch:]
     h = pts
     for i in range(D):
@@ -269,6 +270,51 @@ def test_fp16_pair_rows_of_unequal_size(N):
             assert err["f16x2"][0] <= 1.5 * err["f32"][0] and err["f16x2"][1] <= 2.0 * err["f32"][1], (shift, dead_end, layer, err)
     finally:
         ctx.set_precision(mine)
+
+
+def test_nonfinite_values_born_inside_the_network(N):
+    """An activation that overflows fp32 INSIDE the network, from finite inputs (missing 3): F.relu keeps +inf
+    and NaN (nerf/nerf.py:72), the next Linear mixes inf - inf, and every channel downstream is NaN; v_max_f32 drops NaNs,
+    so the kernels carry the fact along and restore the reference's result. Against the same operations in PyTorch fp32
+    on the CPU: the NaN pattern is the reference's, finite entries agree, in both arithmetic modes."""
+    arch = dict(D=8, skips=[4], use_viewdirs=True, output_ch=4)
+    torch.manual_seed(9)
+    x = torch.rand(700, 90, device="cuda") * 2 - 1
+
+    def scaled(changes, **kw):
+        sd = dict(synthetic.synthetic_state_dict(7, **kw))
+        for key, f in changes.items():
+            sd[key] = (np.asarray(sd[key]) * np.float32(f)).astype(np.float32)
+        return sd
+
+    cases = {
+        # two trunk layers x1e20: h_4 overflows, layer 5 mixes +inf with both signs: everything downstream is NaN
+        "trunk": (scaled({"pts_linears.3.weight": 1e20, "pts_linears.4.weight": 1e20}), arch),
+        # the last trunk layer x1e10 and feature_linear x1e30: the feature vector overflows (both signs: no ReLU there), the
+        # colour branch is NaN, sigma (read from the trunk before feature_linear, nerf.py:86) stays finite
+        "feature": (scaled({"pts_linears.7.weight": 1e10, "feature_linear.weight": 1e30}), arch),
+        # feature_linear and the view layer x1e20 each: the view layer's output overflows, rgb_linear sums +inf with both signs
+        "views": (scaled({"feature_linear.weight": 1e20, "views_linears.0.weight": 1e20}), arch),
+        "trunk, no viewdirs": (scaled({"pts_linears.2.weight": 1e20, "pts_linears.3.weight": 1e20}, use_viewdirs=False, output_ch=5),
+                               dict(D=8, skips=[4], use_viewdirs=False, output_ch=5)),
+    }
+    ctx = N.get_context()
+    ctx.precision_status(reset=True)
+    for name, (sd, ar) in cases.items():
+        want = _forward_fp64(sd, x, 8, [4], ar["use_viewdirs"], dtype=torch.float32)
+        got = cpu(make_net(N, sd, **ar)(x))
+        bad_w, bad_g = ~np.isfinite(want), ~np.isfinite(got)
+        assert bad_w.any(), name
+        if name in ("feature", "views"):
+            assert np.isfinite(want[:, 3]).all()      # sigma is read from the trunk: untouched
+        # where the reference is NaN or infinite, so is the kernel (an infinity of the reference may be a NaN here: DESIGN 8)
+        assert np.array_equal(bad_w, bad_g), (name, bad_w.sum(), bad_g.sum(), np.argwhere(bad_w != bad_g)[:5])
+        assert np.array_equal(np.isnan(want) | np.isinf(want), np.isnan(got) | np.isinf(got))
+        fin = ~bad_w
+        if fin.any():
+            scale = max(1.0, np.abs(want[fin]).max())
+            assert np.abs(got[fin] - want[fin]).max() <= 3e-6 * scale, name
+    ctx.precision_status(reset=True)
 
 
 def _unequal_rows(sd, shift, dead_end, layer, col0):
