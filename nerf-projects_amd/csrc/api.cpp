@@ -414,7 +414,9 @@ int nerf_load_weights(nerf_ctx* c, int slot, const nerf_arch* arch, const float*
         net.n_params = total;
         // index table of the fused backward-data kernel's stream (training; view-dependent networks only)
         net.bwd_table.clear();
-        if (arch->use_viewdirs && arch->W == kWidth) {      // (narrower networks train on the layer-by-layer chain)
+        // (narrower networks, one-layer trunks without a view branch and heads of more than kBwdMaxOutRows channels train on
+        // the layer-by-layer chain)
+        if (arch->W == kWidth && (arch->use_viewdirs || (arch->output_ch <= kBwdMaxOutRows && arch->D >= 2))) {
             float* tsb = nullptr;
             int nbc = 0;
             rc = pack_backward_stream(*arch, fake_ptrs.data(), mask, &tsb, &nbc);

@@ -600,62 +600,81 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
         const int64_t pt = pt_raw < b.n_points ? pt_raw : b.n_points - 1;
         const bool live = pt_raw < b.n_points;
         const float* dr = b.d_raw + pt * b.C;
-        const float d0 = dr[0], d1 = dr[1], d2 = dr[2], dsig = dr[3];
-
         f32x16 hid[8], acc[8];
-        // d(view pre-activation): rgb_linear^T (3 rows, per-register weights: bias-block tiles 8D+22+4c+t) and the mask
+        if (b.use_viewdirs) {
+            const float d0 = dr[0], d1 = dr[1], d2 = dr[2], dsig = dr[3];
+            // d(view pre-activation): rgb_linear^T (3 rows, per-register weights: bias-block tiles 8D+22+4c+t) and the mask
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f32x16 w0 = *(const f32x16*)(bias_lds + ((8 * b.D + 22 + t) * 2 + h) * 16);
-            const f32x16 w1 = *(const f32x16*)(bias_lds + ((8 * b.D + 26 + t) * 2 + h) * 16);
-            const f32x16 w2 = *(const f32x16*)(bias_lds + ((8 * b.D + 30 + t) * 2 + h) * 16);
+            for (int t = 0; t < 4; ++t) {
+                const f32x16 w0 = *(const f32x16*)(bias_lds + ((8 * b.D + 22 + t) * 2 + h) * 16);
+                const f32x16 w1 = *(const f32x16*)(bias_lds + ((8 * b.D + 26 + t) * 2 + h) * 16);
+                const f32x16 w2 = *(const f32x16*)(bias_lds + ((8 * b.D + 30 + t) * 2 + h) * 16);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(d2, w2[r], fmaf(d1, w1[r], d0 * w0[r]));
-        }
-        mask_tiles<4>(hid, acc, b.fwd.hv, b.fwd.hv_ld, pt, h);
-        if (b.maxes) track_max<4>(b.maxes + kBwdMaxViews, hid);
+                for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(d2, w2[r], fmaf(d1, w1[r], d0 * w0[r]));
+            }
+            mask_tiles<4>(hid, acc, b.fwd.hv, b.fwd.hv_ld, pt, h);
+            if (b.maxes) track_max<4>(b.maxes + kBwdMaxViews, hid);
 
-        // every gradient tile goes to memory behind the barrier of the chunk that contracts over it (see run_steps)
-        // d feature = W_views[:, :W]^T d(view pre-activation)
-        zero_tiles<8>(acc);
-        {
-            const RowRef out = row_ref(b.out.hv, b.out.hv_ld, pt, h);
+            // every gradient tile goes to memory behind the barrier of the chunk that contracts over it (see run_steps)
+            // d feature = W_views[:, :W]^T d(view pre-activation)
+            zero_tiles<8>(acc);
+            {
+                const RowRef out = row_ref(b.out.hv, b.out.hv_ld, pt, h);
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-                chunk_ktile8(pipe, cur, acc, hid[kt], [&]() { store_tile_at(out, hid[kt], kt); });
-        }
-        activate<8, false>(hid, acc);
-        if (b.maxes) track_max<8>(b.maxes + kBwdMaxFeat, hid);
+                for (int kt = 0; kt < 4; ++kt)
+                    chunk_ktile8(pipe, cur, acc, hid[kt], [&]() { store_tile_at(out, hid[kt], kt); });
+            }
+            activate<8, false>(hid, acc);
+            if (b.maxes) track_max<8>(b.maxes + kBwdMaxFeat, hid);
 
-        // d h_{D-1} = W_feature^T d feature + d sigma * w_alpha (alpha row: bias-block tiles 8D+14+t), then its mask
-        // The ReLU mask of the layer below is the activation the forward pass kept: 1 KB per point, 128 KB per workgroup
-        // and layer. Read at the layer boundary it stalls the matrix pipe for as long as HBM takes to deliver it (a fifth
-        // of a layer's time, measured); instead tile kt of it is requested behind the barrier of chunk kt + 1, into the
-        // registers of the gradient tile that chunk kt has just finished with, and only tile 7 is waited for in the open.
-        zero_tiles<8>(acc);
-        {
-            const RowRef out = row_ref(b.out.feat, b.out.feat_ld, pt, h);
-            const RowRef kept = row_ref(b.fwd.h[b.D - 1], b.fwd.h_ld[b.D - 1], pt, h);
+            // d h_{D-1} = W_feature^T d feature + d sigma * w_alpha (alpha row: bias-block tiles 8D+14+t), then its mask
+            // The ReLU mask of the layer below is the activation the forward pass kept: 1 KB per point, 128 KB per workgroup
+            // and layer. Read at the layer boundary it stalls the matrix pipe for as long as HBM takes to deliver it (a fifth
+            // of a layer's time, measured); instead tile kt of it is requested behind the barrier of chunk kt + 1, into the
+            // registers of the gradient tile that chunk kt has just finished with, and only tile 7 is waited for in the open.
+            zero_tiles<8>(acc);
+            {
+                const RowRef out = row_ref(b.out.feat, b.out.feat_ld, pt, h);
+                const RowRef kept = row_ref(b.fwd.h[b.D - 1], b.fwd.h_ld[b.D - 1], pt, h);
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt)
-                chunk_ktile8(pipe, cur, acc, hid[kt], [&]() {
-                    store_tile_at(out, hid[kt], kt);
-                    if (kt >= 1) load_tile_at(kept, hid[kt - 1], kt - 1);
-                });
-            load_tile_at(kept, hid[7], 7);
+                for (int kt = 0; kt < 8; ++kt)
+                    chunk_ktile8(pipe, cur, acc, hid[kt], [&]() {
+                        store_tile_at(out, hid[kt], kt);
+                        if (kt >= 1) load_tile_at(kept, hid[kt - 1], kt - 1);
+                    });
+                load_tile_at(kept, hid[7], 7);
+            }
+            // (the stream carries the alpha row as an MFMA column here for the fp16-pair kernel; this kernel adds the rank-1 term
+            // below and only keeps the ring turning)
+            consume_chunk<8>(pipe, cur, [&](auto, auto, const Frag16&) {});
+            if (b.maxes) track_max<8>(b.maxes + kBwdMaxKept + b.D - 1, hid);      // the kept h_{D-1}, before it becomes d z_{D-1}
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const f32x16 wa = *(const f32x16*)(bias_lds + ((8 * b.D + 14 + t) * 2 + h) * 16);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(dsig, wa[r], acc[t][r]);
+                mask_tile(hid[t], acc[t]);
+            }
+            if (b.maxes) track_max<8>(b.maxes + b.D - 1, hid);
+        } else {
+            // output_linear (nerf.py:109): d h_{D-1} = W_output^T d raw over the C <= kBwdMaxOutRows channels (rows per register:
+            // bias-block tiles 8D+1+8c+t), masked by the kept h_{D-1}
+            zero_tiles<8>(acc);
+            for (int c = 0; c < b.C; ++c) {
+                const float dc = dr[c];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const f32x16 w = *(const f32x16*)(bias_lds + ((8 * b.D + 1 + 8 * c + t) * 2 + h) * 16);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(dc, w[r], acc[t][r]);
+                }
+            }
+            load_tiles<8>(b.fwd.h[b.D - 1], b.fwd.h_ld[b.D - 1], hid, pt, h);
+            if (b.maxes) track_max<8>(b.maxes + kBwdMaxKept + b.D - 1, hid);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) mask_tile(hid[t], acc[t]);
+            if (b.maxes) track_max<8>(b.maxes + b.D - 1, hid);
         }
-        // (the stream carries the alpha row as an MFMA column here for the fp16-pair kernel; this kernel adds the rank-1 term
-        // below and only keeps the ring turning)
-        consume_chunk<8>(pipe, cur, [&](auto, auto, const Frag16&) {});
-        if (b.maxes) track_max<8>(b.maxes + kBwdMaxKept + b.D - 1, hid);      // the kept h_{D-1}, before it becomes d z_{D-1}
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const f32x16 wa = *(const f32x16*)(bias_lds + ((8 * b.D + 14 + t) * 2 + h) * 16);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(dsig, wa[r], acc[t][r]);
-            mask_tile(hid[t], acc[t]);
-        }
-        if (b.maxes) track_max<8>(b.maxes + b.D - 1, hid);
 
         // trunk: d h_{i-1} = W_i[:, hidden]^T d z_i, masked by layer i-1's ReLU
         for (int i = b.D - 1; i >= 1; --i) {
@@ -681,11 +700,12 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
 
 hipError_t launch_mlp_bwd(const MlpBwdLaunch& b, hipStream_t s) {
     if (b.n_points <= 0) return hipSuccess;
-    if (b.n_chunks != 13 + 8 * (b.D - 1) || b.C < 4) return hipErrorInvalidValue;
+    if (b.n_chunks != (b.use_viewdirs ? 13 : 0) + 8 * (b.D - 1) || b.C < 4) return hipErrorInvalidValue;
+    if (!b.use_viewdirs && (b.C > kBwdMaxOutRows || b.n_bias_tiles < 8 * b.D + 1 + 8 * b.C || b.D < 2)) return hipErrorInvalidValue;
     if (b.n_points > (int64_t)1 << 22) return hipErrorInvalidValue;      // 32-bit element offsets in load/store_tiles
     // the hooks inside the chunk loop are unconditional 16-byte accesses (RowRef)
-    bool rows_ok = training_rows_ok(b.out.hv, b.out.hv_ld) && training_rows_ok(b.out.feat, b.out.feat_ld) &&
-                   training_rows_ok(b.fwd.hv, b.fwd.hv_ld);
+    bool rows_ok = !b.use_viewdirs || (training_rows_ok(b.out.hv, b.out.hv_ld) && training_rows_ok(b.out.feat, b.out.feat_ld) &&
+                                       training_rows_ok(b.fwd.hv, b.fwd.hv_ld));
     for (int i = 0; i < b.D; ++i) rows_ok = rows_ok && training_rows_ok(b.out.h[i], b.out.h_ld[i]) && training_rows_ok(b.fwd.h[i], b.fwd.h_ld[i]);
     if (!rows_ok) return hipErrorInvalidValue;
     const int64_t tiles = (b.n_points + kPointsPerGroup - 1) / kPointsPerGroup;

@@ -22,6 +22,7 @@ constexpr int kBiasTileFloats = 32;          // [h(2)][16 accumulator registers]
 constexpr int kBiasLdsBytes = 20480;         // up to 160 bias / row-vector tiles
 constexpr int kWidth = 256;                  // trunk width this build is specialised for
 constexpr int kMaxDepth = 12;
+constexpr int kBwdMaxOutRows = 8;           // output_linear rows the fused backward-data kernel takes per register (no viewdirs)
 constexpr int kPointsPerWave = 32;
 constexpr int kWavesPerGroup = 4;
 constexpr int kPointsPerGroup = kPointsPerWave * kWavesPerGroup;
@@ -187,6 +188,7 @@ struct MlpBwdLaunch {
     int64_t n_points;
     const float* d_raw;      // [P, C]: d rgb (0..2), d sigma (3)
     int C;
+    int use_viewdirs;        // 0: output_linear head (C <= kBwdMaxOutRows rows, nerf.py:109): fp32 kernel only
     MlpStore fwd;            // the activations the forward pass kept (ReLU masks): h[i], hv
     MlpStore out;            // h[i] = d(pre-activation of trunk layer i), feat = d feature, hv = d(view pre-activation)
     // optional [kBwdMaxSlots], zeroed by the caller: the largest |value| of what this pass writes and reads, as float bits

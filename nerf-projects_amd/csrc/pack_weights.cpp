@@ -125,8 +125,9 @@ std::vector<int> chunk_layers(const nerf_arch& a, uint32_t mask) {
 // `tensors` in state_dict order as for pack_weights; validated there.
 int pack_backward_stream(const nerf_arch& a, const float* const* tensors, uint32_t mask, float** stream_out,
                          int* n_chunks) {
-    if (!a.use_viewdirs || a.W != kWidth) {
-        set_error("pack_backward_stream: view-dependent networks of width %d only", kWidth);
+    if (a.W != kWidth || (!a.use_viewdirs && a.output_ch > kBwdMaxOutRows)) {
+        set_error("pack_backward_stream: networks of width %d (without view directions: at most %d output channels) only", kWidth,
+                  kBwdMaxOutRows);
         return NERF_E_INVALID;
     }
     Stream st;
@@ -134,9 +135,11 @@ int pack_backward_stream(const nerf_arch& a, const float* const* tensors, uint32
         for (int kt = 0; kt < n_kt; ++kt) chunk_ktile(st, T, 8, [kt](int t, int h) { return hid_col(kt, t, h); });
     };
     const float* const* head = tensors + 2 * a.D + 2;
-    layer(LinearT{tensors[2 * a.D], a.W, a.W / 2, a.W + a.input_ch_views, 0}, 4);
-    layer(LinearT{head[0], a.W, a.W, a.W, 0}, 8);
-    chunk_ktile(st, ColumnOf{head[2], a.W}, 8, [](int t, int h) { return hid_col(0, t, h); });
+    if (a.use_viewdirs) {
+        layer(LinearT{tensors[2 * a.D], a.W, a.W / 2, a.W + a.input_ch_views, 0}, 4);
+        layer(LinearT{head[0], a.W, a.W, a.W, 0}, 8);
+        chunk_ktile(st, ColumnOf{head[2], a.W}, 8, [](int t, int h) { return hid_col(0, t, h); });
+    }      // (without view directions the chain starts at d h_{D-1} = W_output^T d raw, a vector product in the kernel)
     for (int i = a.D - 1; i >= 1; --i) {
         const bool pe_in = (mask >> i) & 1;
         layer(LinearT{tensors[2 * i], a.W, a.W, pe_in ? a.W + a.input_ch : a.W, pe_in ? a.input_ch : 0}, 8);
@@ -301,6 +304,11 @@ int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors,
             for (int t4 = 0; t4 < 4; ++t4)
                 fill_group(c, kt * 4 + t4, outl, 0, t4, hid(kt, 0, a.W));
         bias_tiles(bias, outl, 1);
+        // output_linear's rows once more per accumulator register (tiles 8D+1+8c .. +8 for row c): the backward-data pass of
+        // the training step turns d raw into d h_{D-1} with them (nerf_mlp_bwd_kernel); only for the channel counts the
+        // reference builds (4, or 5 with N_importance > 0, nerf.ipynb:885) - a 32-channel head would not fit the bias block
+        if (a.output_ch <= kBwdMaxOutRows)
+            for (int c = 0; c < a.output_ch; ++c) row_tiles(bias, outl, c, 8);
         *out_ch = a.output_ch;
     }
     const size_t ns = st.data.size(), nb = bias.size();

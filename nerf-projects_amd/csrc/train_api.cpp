@@ -418,9 +418,12 @@ bool gemm_backward_requested() {
     return on;
 }
 
+int backward_pass_fused_noviews(Pass& ps, const TnScratch& sc, hipStream_t s);
+
 int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     const PackedNet& net = *ps.net;
     const nerf_arch& a = net.arch;
+    if (!a.use_viewdirs) return backward_pass_fused_noviews(ps, sc, s);
     const LinearDesc &views = net.linears[a.D], &feat = net.linears[a.D + 1], &alpha = net.linears[a.D + 2],
                      &rgb = net.linears[a.D + 3];
     float* d_feat = ps.g_a;      // [P, W]
@@ -438,6 +441,7 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     b.n_points = ps.P;
     b.d_raw = ps.d_raw;
     b.C = ps.C;
+    b.use_viewdirs = 1;
     for (int i = 0; i < a.D; ++i) {
         b.fwd.h[i] = ps.h[i];
         b.fwd.h_ld[i] = ps.h_ld[i];
@@ -526,6 +530,86 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
         b->accumulate = sc.accumulate;
         TrainTimer timer(ps.ctx, s, b == &narrow ? 3 : 2, ps.P);
         HIP_TRY(launch_grad_batch(*b, b != &narrow, sc.part, sc.part_floats, sc.dbp, sc.dbp_floats, s, b == &pairs));
+    }
+    return NERF_OK;
+}
+
+// Networks without view directions (use_viewdirs=False: output_linear on the trunk, nerf.py:109): the same fused fp32 launch
+// from d raw to every pre-activation gradient - the head's transpose as vector products inside the kernel - then the trunk's
+// weight gradients batched as above and output_linear's as one small job. views_linears exists in the module
+// (nerf/nerf.py:43) and is never evaluated: its gradient is zero.
+int backward_pass_fused_noviews(Pass& ps, const TnScratch& sc, hipStream_t s) {
+    const PackedNet& net = *ps.net;
+    const nerf_arch& a = net.arch;
+    const LinearDesc &views = net.linears[a.D], &out = net.linears[a.D + 1];
+    {
+        const int rc = refresh_bwd(const_cast<PackedNet&>(net), false, false, s);
+        if (rc != NERF_OK) return rc;
+    }
+    MlpBwdLaunch b{};
+    b.stream = net.train.d_stream_bwd;
+    b.n_chunks = net.train.n_chunks_bwd;
+    b.bias = net.d_bias;
+    b.n_bias_tiles = net.n_bias_tiles;
+    b.D = a.D;
+    b.n_points = ps.P;
+    b.d_raw = ps.d_raw;
+    b.C = ps.C;
+    b.use_viewdirs = 0;
+    for (int i = 0; i < a.D; ++i) {
+        b.fwd.h[i] = ps.h[i];
+        b.fwd.h_ld[i] = ps.h_ld[i];
+        b.out.h[i] = ps.dz[i];
+        b.out.h_ld[i] = a.W;
+    }
+    const bool pair_dw = ps.precision == NERF_PRECISION_F16X2 && pair_dw_allowed() && ps.maxes != nullptr;
+    if (pair_dw) b.maxes = ps.maxes;
+    {
+        TrainTimer timer(ps.ctx, s, 1, ps.P);
+        HIP_TRY(launch_mlp_bwd(b, s));
+    }
+    int rc;
+    if ((rc = grad_linear(net, out, ps.d_raw, ps.C, ps.h[a.D - 1], ps.h_ld[a.D - 1], ps.P, sc, s))) return rc;
+    if (!sc.accumulate)
+        HIP_TRY(hipMemsetAsync(net.train.d_grad + views.w_off, 0, ((size_t)views.out * views.in + views.out) * sizeof(float), s));
+    float* grad = net.train.d_grad;
+    GradBatch wide{}, narrow{}, pairs{};
+    auto job = [&](GradBatch& bt, const LinearDesc& d, const float* dY, const float* X, int ldx, int n0, int n1, bool with_db,
+                   const unsigned* a_max = nullptr, const unsigned* b_max = nullptr) {
+        bt.job[bt.n++] = GradJob{dY, a.W, X, ldx, d.out, n0, n1, grad + d.w_off, d.in, with_db ? grad + d.b_off : nullptr,
+                                 nullptr, nullptr, a_max, b_max, GradExps{nullptr, nullptr, 0, 0}};
+    };
+    if (a.input_ch > 64 || a.D > kMaxGradJobs) {
+        for (int i = a.D - 1; i >= 0; --i)
+            if ((rc = grad_linear(net, net.linears[i], ps.dz[i], a.W, ps.in[i], ps.in_ld[i], ps.P, sc, s))) return rc;
+        return NERF_OK;
+    }
+    GradBatch& hidden = pair_dw ? pairs : wide;
+    for (int i = a.D - 1; i >= 0; --i) {
+        const LinearDesc& d = net.linears[i];
+        if (d.in >= a.W) {
+            const int lead = d.in - a.W;                                               // cat[gamma(x), h] (nerf.py:79-80)
+            job(hidden, d, ps.dz[i], ps.in[i], ps.in_ld[i], lead, d.in, true, pair_dw ? ps.maxes + i : nullptr,
+                pair_dw ? ps.maxes + kBwdMaxKept + i - 1 : nullptr);
+            if (lead > 0) job(narrow, d, ps.dz[i], ps.in[i], ps.in_ld[i], 0, lead, false);
+        } else {
+            job(narrow, d, ps.dz[i], ps.in[i], ps.in_ld[i], 0, d.in, true);            // layer 0: gamma(x) only
+        }
+    }
+    for (GradBatch* bt : {&pairs, &wide, &narrow}) {
+        if (bt->n == 0) continue;
+        int n_slices = 256 / bt->n;
+        const int64_t cap = (ps.P + 255) / 256;
+        if (n_slices > cap) n_slices = (int)cap;
+        if (n_slices < 1) n_slices = 1;
+        int64_t pps = (ps.P + n_slices - 1) / n_slices;
+        pps = (pps + kSlicePointQuantum - 1) / kSlicePointQuantum * kSlicePointQuantum;
+        bt->n_slices = n_slices;
+        bt->pts_per_slice = pps;
+        bt->P = ps.P;
+        bt->accumulate = sc.accumulate;
+        TrainTimer timer(ps.ctx, s, bt == &narrow ? 3 : 2, ps.P);
+        HIP_TRY(launch_grad_batch(*bt, bt != &narrow, sc.part, sc.part_floats, sc.dbp, sc.dbp_floats, s, bt == &pairs));
     }
     return NERF_OK;
 }
@@ -696,7 +780,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     pc.N = N;
     pc.P = Pc;
     pc.S = Sc;
-    pc.fused_backward = !gemm_backward_requested() && nc.train.d_stream_bwd != nullptr && nc.out_ch == 4;
+    pc.fused_backward = !gemm_backward_requested() && nc.train.d_stream_bwd != nullptr && (nc.out_ch == 4 || !nc.arch.use_viewdirs);
     pc.precision = precision;
     pc.ctx = c;
     pc.loose = c->d_loose;
@@ -708,7 +792,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
         pf.N = N;
         pf.P = Pf;
         pf.S = Sf;
-        pf.fused_backward = !gemm_backward_requested() && nf.train.d_stream_bwd != nullptr && nf.out_ch == 4;
+        pf.fused_backward = !gemm_backward_requested() && nf.train.d_stream_bwd != nullptr && (nf.out_ch == 4 || !nf.arch.use_viewdirs);
         pf.precision = precision;
         pf.ctx = c;
         pf.loose = c->d_loose;

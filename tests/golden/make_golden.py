@@ -603,6 +603,33 @@ def gold_widths():
     save("widths", **out)
 
 
+def gold_train_noviewdirs():
+    """One iteration of the training loop body (nerf.ipynb:1258-1275) for networks WITHOUT view directions
+    (use_viewdirs=False: input_ch_views = 0, a 5-channel output_linear whose last channel nothing reads, nerf.ipynb:879-885;
+    8-column rays), coarse + fine, with the reference's pytest RNG: losses, gradient norms and every 61st element.
+    views_linears.0.* exists in the module (nerf/nerf.py:43) and never receives a gradient."""
+    g = np.load(os.path.join(HERE, "render_rays_lego.npz"))
+    rays = torch.from_numpy(g["rays"][:32, :8].copy())
+    target = torch.from_numpy(np.random.RandomState(106).uniform(0, 1, size=(32, 3)).astype(np.float32))
+    arch = dict(input_ch_views=0, use_viewdirs=False, output_ch=5)
+    net_c, net_f = ref_model(8, **arch), ref_model(48, **arch)
+    net_c.train(); net_f.train()
+    e_fn, _ = ref_embedder.get_embedder(10, 0)
+    kw = dict(N_samples=64, N_importance=128, retraw=True, white_bkgd=True, perturb=1.0, raw_noise_std=1.0, pytest=True)
+    r = NS["render_rays"](rays, net_c, query_fn(e_fn, None), network_fine=net_f, **kw)
+    img_loss, img_loss0 = ref_helpers.img2mse(r["rgb_map"], target), ref_helpers.img2mse(r["rgb0"], target)
+    (img_loss + img_loss0).backward()
+    out = dict(rays=n(rays), target=n(target), img_loss=n(img_loss), img_loss0=n(img_loss0), rgb=n(r["rgb_map"]),
+               digest_c=synthetic.state_dict_digest(synthetic.synthetic_state_dict(8, **arch)),
+               digest_f=synthetic.state_dict_digest(synthetic.synthetic_state_dict(48, **arch)))
+    for tag, net in (("c", net_c), ("f", net_f)):
+        for k, p in net.named_parameters():
+            gr = n(p.grad).reshape(-1) if p.grad is not None else np.zeros(p.numel(), np.float32)
+            out[f"gnorm_{tag}.{k}"] = np.linalg.norm(gr.astype(np.float64))
+            out[f"gsub_{tag}.{k}"] = gr[::61].copy()
+    save("train_step_noviewdirs", **out)
+
+
 def gold_llff_pose_math():
     """The pure-numpy pose functions of nerf/load_llff.py, executed from its source (the module itself
     cannot be imported here: it needs imageio). Only function definitions that touch numpy alone are
@@ -746,5 +773,6 @@ if __name__ == "__main__":
     gold_train_variants()
     gold_train_adam_state()
     gold_widths()
+    gold_train_noviewdirs()
     gold_llff_pose_math()
     gold_tiny_scene()

@@ -74,7 +74,8 @@ int main(int argc, char** argv) {
         fprintf(stderr, "pack_weights: %s\n", nerf::g_err);
         return 3;
     }
-    if (a.use_viewdirs && a.W == nerf::kWidth) {      // (the fused backward pass exists for the full width only)
+    // (the fused backward pass exists for the full width; without view directions for heads of at most kBwdMaxOutRows channels)
+    if (a.W == nerf::kWidth && (a.use_viewdirs || (a.output_ch <= nerf::kBwdMaxOutRows && a.D >= 2))) {
         rc = nerf::pack_backward_stream(a, tensors.data(), mask, &bwd, &n_bwd);
         if (rc != NERF_OK) {
             fprintf(stderr, "pack_backward_stream: %s\n", nerf::g_err);

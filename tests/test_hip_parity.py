@@ -593,6 +593,36 @@ def test_train_step_width_128(N):
     assert np.abs(cpu(net_c(x)) - before).max() > 1e-6
 
 
+def test_train_gradients_without_viewdirs(N):
+    """One training iteration of a coarse + fine pair WITHOUT view directions (use_viewdirs=False: input_ch_views = 0, a
+    5-channel output_linear, 8-column rays; nerf.ipynb:879-885) against the reference's autograd
+    (tests/golden/train_step_noviewdirs.npz): both losses, every gradient tensor (views_linears.0.* exists in the module and
+    never receives a gradient: zeros), bars of test_train_gradients_match_autograd. Since round 3 this configuration takes
+    the fused backward-data launch too (the head's transpose as vector products in the kernel) instead of the layer-by-layer
+    chain (NERF_TRAIN_GEMM_BACKWARD=1 keeps the chain)."""
+    g = load_golden("train_step_noviewdirs")
+    arch = dict(input_ch_views=0, use_viewdirs=False, output_ch=5)
+    sd_c, sd_f = synthetic.synthetic_state_dict(8, **arch), synthetic.synthetic_state_dict(48, **arch)
+    assert synthetic.state_dict_digest(sd_c) == str(g["digest_c"]) and synthetic.state_dict_digest(sd_f) == str(g["digest_f"])
+    net_c, net_f = make_net(N, sd_c, **arch), make_net(N, sd_f, **arch)
+    rays = g["rays"]
+    kw = dict(network_fn=net_c, network_fine=net_f, N_samples=64, N_importance=128, white_bkgd=True, perturb=1.0,
+              raw_noise_std=1.0, pytest=True, ndc=False, use_viewdirs=False, near=2., far=6.)
+    opt = N.Adam([net_c, net_f], lr=5e-4)
+    out = N.train_on_batch(800, 800, None, (gpu(rays[:, 0:3]), gpu(rays[:, 3:6])), gpu(g["target"]), opt, apply_update=False, **kw)
+    assert abs(float(out["img_loss"]) - float(g["img_loss"])) <= 2e-6
+    assert abs(float(out["img_loss0"]) - float(g["img_loss0"])) <= 2e-6
+    for tag, net in (("c", net_c), ("f", net_f)):
+        for k, gr in net.grad_dict().items():
+            gr = gr.numpy().reshape(-1)
+            want_norm, want_sub = float(g[f"gnorm_{tag}.{k}"]), g[f"gsub_{tag}.{k}"]
+            tol = 2e-5 if tag == "c" else 2e-4
+            assert abs(np.linalg.norm(gr.astype(np.float64)) - want_norm) <= tol * want_norm + 1e-9, (tag, k)
+            assert np.abs(gr[::61] - want_sub).max() <= 5 * tol * (np.abs(want_sub).max() + 1e-12) + 1e-9, (tag, k)
+            if k.startswith("views_linears"):
+                assert not gr.any()
+
+
 def test_run_network_fused_matches_staged(N, O):
     """Fused encode+MLP == embed kernel -> cat -> MLP kernel, and both == oracle."""
     g = load_golden("mlp_forward")

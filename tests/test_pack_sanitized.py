@@ -198,7 +198,15 @@ def repack(D, W, in_ch, in_v, out_ch, viewdirs, skips):
         stream.append(chunk_row(outl, W))
         ids.append(D)
         bias += bias_tiles(outl, 1)
+        if out_ch <= 8:      # output_linear's rows per accumulator register, for the fused backward pass
+            for c in range(out_ch):
+                bias += row_tiles(outl, c, 8)
         n_out = out_ch
+    if not viewdirs and W == 256 and out_ch <= 8 and D >= 2:
+        for i in range(D - 1, 0, -1):      # backward stream without a view branch: the trunk's transposes only
+            for kt in range(8):
+                bwd.append(chunk_ktile(LinT(lins[i], W, W, in_ch if (mask >> i) & 1 else 0), 8,
+                                       lambda t, h, kt=kt: hidden_col(kt, t, h)))
     if viewdirs and W == 256:
         # backward stream: W_views[:, :W]^T (4 k-tiles), W_feature^T, the alpha column, W_i[:, hidden]^T for i = D-1..1
         def layer_t(T, n_kt):  # noqa: E306
