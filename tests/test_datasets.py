@@ -191,3 +191,58 @@ def test_llff_loader_on_the_committed_scene():
         with pytest.raises(RuntimeError) as e:
             datasets._load_data(os.path.join(SCENE, "llff"), **kw)
         assert "images_12x8" in str(e.value)
+
+
+def test_minify_runs_mogrify_as_the_reference_does(tmp_path, monkeypatch):
+    """The branch of _load_data / _minify that creates a missing down-sampled folder with ImageMagick
+    (load_llff.py:8-62: `cp images/* images_4/`, `mogrify -resize 25% -format png *.jpg` inside it, `rm *.jpg`) - ImageMagick is
+    not installed here, so a stand-in `mogrify` on PATH records how it was called and does the resize with Pillow: what is
+    checked is the COMMAND LINE, the working directory and what the loader makes of the result (folder contents, image shapes,
+    the hwf column), for the `factor=` and the `height=` forms."""
+    import shutil
+    import stat
+    import sys
+    pytest.importorskip("PIL")
+    scene = tmp_path / "scene"
+    shutil.copytree(os.path.join(SCENE, "llff", "images"), scene / "images")
+    shutil.copy(os.path.join(SCENE, "llff", "poses_bounds.npy"), scene / "poses_bounds.npy")
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    log = tmp_path / "mogrify.log"
+    stub = bindir / "mogrify"
+    stub.write_text(f"""#!{sys.executable}
+import json, os, sys
+from PIL import Image
+args = sys.argv[1:]
+with open({str(log)!r}, "a") as f:
+    f.write(json.dumps({{"args": args, "cwd": os.getcwd()}}) + "\\n")
+assert args[0] == "-resize" and args[2] == "-format" and args[3] == "png", args
+spec, files = args[1], args[4:]
+for name in files:
+    im = Image.open(name)
+    if spec.endswith("%"):
+        w, h = (max(1, round(s * float(spec[:-1]) / 100.0)) for s in im.size)
+    else:
+        w, h = (int(v) for v in spec.split("x"))
+    im.resize((w, h), Image.BOX).save(os.path.splitext(name)[0] + ".png")
+""")
+    stub.chmod(stub.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ["PATH"])
+    images, poses, bds, render_poses, i_test = datasets.load_llff_data(str(scene), factor=4)
+    import json
+    calls = [json.loads(l) for l in log.read_text().splitlines()]
+    assert len(calls) == 1
+    assert calls[0]["cwd"] == str(scene / "images_4")                           # run inside the new folder (load_llff.py:53-55)
+    assert calls[0]["args"][:4] == ["-resize", "25.0%", "-format", "png"]       # '{}%'.format(100. / r), load_llff.py:35
+    assert sorted(calls[0]["args"][4:]) == [f"img_{i:03d}.jpg" for i in range(5)]      # the shell expanded *.jpg on the copies
+    assert sorted(os.listdir(scene / "images_4")) == [f"img_{i:03d}.png" for i in range(5)]      # originals removed (:57-59)
+    assert images.shape == (5, 4, 6, 3) and images.dtype == np.float32
+    assert poses[0, 0, 4] == 4 and poses[0, 1, 4] == 6 and abs(poses[0, 2, 4] - 407.5 / 4) < 1e-3
+    # a second load finds the folder and does not call mogrify again
+    datasets.load_llff_data(str(scene), factor=4)
+    assert len(log.read_text().splitlines()) == 1
+    # height=: the folder name and the resize argument carry WxH derived from the full-size images (load_llff.py:77-87)
+    raw = datasets._load_data(str(scene), height=8)
+    calls = [json.loads(l) for l in log.read_text().splitlines()]
+    assert len(calls) == 2 and calls[1]["cwd"] == str(scene / "images_12x8") and calls[1]["args"][1] == "12x8"
+    assert raw[2].shape == (8, 12, 3, 5) and raw[0][0, 4, 0] == 8 and raw[0][1, 4, 0] == 12
