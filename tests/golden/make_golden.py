@@ -630,6 +630,33 @@ def gold_train_noviewdirs():
     save("train_step_noviewdirs", **out)
 
 
+def gold_train_depths():
+    """One training iteration (nerf.ipynb:1258-1275, the reference's pytest RNG) for trunks of other depths and skip sets
+    than the shipped 8 / [4]: D = 3 with a skip at 0 (an odd number of layers), D = 4 with a skip at 1, D = 2 without a
+    skip - coarse + fine pairs; losses, gradient norms and every 61st element."""
+    g = np.load(os.path.join(HERE, "render_rays_lego.npz"))
+    rays = torch.from_numpy(g["rays"][:32])
+    target = torch.from_numpy(np.random.RandomState(106).uniform(0, 1, size=(32, 3)).astype(np.float32))
+    e_fn, _ = ref_embedder.get_embedder(10, 0)
+    ed_fn, _ = ref_embedder.get_embedder(4, 0)
+    kw = dict(N_samples=64, N_importance=128, retraw=True, white_bkgd=True, perturb=1.0, raw_noise_std=1.0, pytest=True)
+    out = dict(rays=n(rays), target=n(target))
+    for tag, seeds, arch in (("d3", (61, 62), dict(D=3, skips=(0,))), ("d4", (63, 64), dict(D=4, skips=(1,))),
+                             ("d2", (65, 66), dict(D=2, skips=()))):
+        net_c, net_f = ref_model(seeds[0], **arch), ref_model(seeds[1], **arch)
+        net_c.train(); net_f.train()
+        r = NS["render_rays"](rays, net_c, query_fn(e_fn, ed_fn), network_fine=net_f, **kw)
+        img_loss, img_loss0 = ref_helpers.img2mse(r["rgb_map"], target), ref_helpers.img2mse(r["rgb0"], target)
+        (img_loss + img_loss0).backward()
+        out[f"{tag}.img_loss"], out[f"{tag}.img_loss0"] = n(img_loss), n(img_loss0)
+        for which, net in (("c", net_c), ("f", net_f)):
+            for k, p in net.named_parameters():
+                gr = n(p.grad).reshape(-1) if p.grad is not None else np.zeros(p.numel(), np.float32)
+                out[f"{tag}.gnorm_{which}.{k}"] = np.linalg.norm(gr.astype(np.float64))
+                out[f"{tag}.gsub_{which}.{k}"] = gr[::61].copy()
+    save("train_step_depths", **out)
+
+
 def gold_llff_pose_math():
     """The pure-numpy pose functions of nerf/load_llff.py, executed from its source (the module itself
     cannot be imported here: it needs imageio). Only function definitions that touch numpy alone are
@@ -774,5 +801,6 @@ if __name__ == "__main__":
     gold_train_adam_state()
     gold_widths()
     gold_train_noviewdirs()
+    gold_train_depths()
     gold_llff_pose_math()
     gold_tiny_scene()

@@ -623,6 +623,33 @@ def test_train_gradients_without_viewdirs(N):
                 assert not gr.any()
 
 
+@pytest.mark.parametrize("tag,seeds,arch", [("d3", (61, 62), dict(D=3, skips=(0,))), ("d4", (63, 64), dict(D=4, skips=(1,))),
+                                            ("d2", (65, 66), dict(D=2, skips=()))])
+def test_train_gradients_other_depths(N, tag, seeds, arch):
+    """One training iteration for trunks of other depths and skip sets than the shipped 8 / [4] - an odd number of layers,
+    a skip right behind layer 0, no skip at all - against the reference's autograd (tests/golden/train_step_depths.npz), in
+    both arithmetics: the fused kernels walk the layers in a loop of two alternating accumulator sets, so depth parity and
+    the position of the concatenated layer are paths of their own. Bars of test_train_gradients_match_autograd."""
+    g = load_golden("train_step_depths")
+    mk = dict(D=arch["D"], skips=list(arch["skips"]))
+    net_c = make_net(N, synthetic.synthetic_state_dict(seeds[0], **arch), **mk)
+    net_f = make_net(N, synthetic.synthetic_state_dict(seeds[1], **arch), **mk)
+    rays = g["rays"]
+    kw = dict(network_fn=net_c, network_fine=net_f, N_samples=64, N_importance=128, white_bkgd=True, perturb=1.0,
+              raw_noise_std=1.0, pytest=True, ndc=False, use_viewdirs=True, near=2., far=6.)
+    opt = N.Adam([net_c, net_f], lr=5e-4)
+    out = N.train_on_batch(800, 800, None, (gpu(rays[:, 0:3]), gpu(rays[:, 3:6])), gpu(g["target"]), opt, apply_update=False, **kw)
+    assert abs(float(out["img_loss"]) - float(g[f"{tag}.img_loss"])) <= 2e-6
+    assert abs(float(out["img_loss0"]) - float(g[f"{tag}.img_loss0"])) <= 2e-6
+    for which, net in (("c", net_c), ("f", net_f)):
+        for k, gr in net.grad_dict().items():
+            gr = gr.numpy().reshape(-1)
+            want_norm, want_sub = float(g[f"{tag}.gnorm_{which}.{k}"]), g[f"{tag}.gsub_{which}.{k}"]
+            tol = 2e-5 if which == "c" else 2e-4
+            assert abs(np.linalg.norm(gr.astype(np.float64)) - want_norm) <= tol * want_norm + 1e-9, (which, k)
+            assert np.abs(gr[::61] - want_sub).max() <= 5 * tol * (np.abs(want_sub).max() + 1e-12) + 1e-9, (which, k)
+
+
 def test_run_network_fused_matches_staged(N, O):
     """Fused encode+MLP == embed kernel -> cat -> MLP kernel, and both == oracle."""
     g = load_golden("mlp_forward")
