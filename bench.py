@@ -74,6 +74,21 @@ def parse():
     return p.parse_args()
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on stdout when a communicator is created; the contract is ONE JSON line there. File
+    descriptor 1 points at stderr while the process group and its first collective come up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def self_launch_command(argv, n_gpus, port=None):
     """The torch.distributed.run command line a plain `python bench.py --gpus N ...` turns into (one rank per GPU of this
     node over RCCL; 127.0.0.1 because a container's hostname may not resolve)."""
@@ -306,7 +321,8 @@ def main():
     use_dist = world > 1 or (args.force_collective and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import nerf_projects_amd as N
     from nerf_projects_amd import synthetic
@@ -351,7 +367,9 @@ def main():
     if use_dist:
         # RCCL opens its point-to-point connections on first use: one tiny gather before anything is timed, so that a
         # run with --warmup 0 does not time communicator setup (this is not a render step)
-        N.gather_frame({"acc_map": torch.zeros(1, device="cuda")}, world, force_collective=True)
+        with stdout_to_stderr():
+            N.gather_frame({"acc_map": torch.zeros(1, device="cuda")}, world, force_collective=True)
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()

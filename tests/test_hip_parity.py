@@ -1225,6 +1225,8 @@ def test_bench_plain_call_launches_itself(N):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "torch.distributed.run" in out.stderr
+    assert [l for l in out.stdout.splitlines() if l.strip()] == [l for l in out.stdout.splitlines() if l.startswith("{")], \
+        out.stdout[:500]            # the contract line and nothing else (RCCL's banner goes to stderr)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["metric"] == "ray_samples_per_sec" and d["n_gpus"] == 1 and d["n_ranks_seen"] == 1 and d["value"] > 1e7
