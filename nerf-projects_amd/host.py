@@ -1121,7 +1121,7 @@ def save_checkpoint(path, global_step, network_fn, network_fine, optimizer):
 def train_on_batch(H, W, K, batch_rays, target_s, optimizer, chunk=1024 * 32, ndc=True, near=0., far=1.,
                    use_viewdirs=False, network_fn=None, network_query_fn=None, N_samples=64, N_importance=0,
                    network_fine=None, perturb=0., raw_noise_std=0., white_bkgd=False, lindisp=False, pytest=False,
-                   apply_update=True, **unused):
+                   apply_update=True, _packed_rays=None, **unused):
     """One iteration of the reference's training loop body (nerf.ipynb:1258-1282) on the GPU:
     ``render(H, W, K, rays=batch_rays, retraw=True, **render_kwargs_train)``, ``img_loss =
     img2mse(rgb, target_s)`` (``+ img2mse(rgb0, target_s)``), ``loss.backward()``, ``optimizer.step()``.
@@ -1130,7 +1130,10 @@ def train_on_batch(H, W, K, batch_rays, target_s, optimizer, chunk=1024 * 32, nd
     if not isinstance(network_fn, NeRF) or (network_fine is not None and not isinstance(network_fine, NeRF)):
         raise TypeError("train_on_batch needs this package's NeRF models")
     ctx = network_fn.ctx
-    packed, _ = pack_rays(H, W, K, batch_rays, None, ndc, near, far, use_viewdirs, None, device=ctx.device)
+    if _packed_rays is not None:      # (tests: a ray record exactly as the reference's render() packed it, e.g. NDC-warped)
+        packed = _dev(_packed_rays, ctx)
+    else:
+        packed, _ = pack_rays(H, W, K, batch_rays, None, ndc, near, far, use_viewdirs, None, device=ctx.device)
     packed = packed.contiguous()
     target = _dev(target_s, ctx).reshape(-1, 3)
     N, stride = packed.shape

@@ -657,6 +657,48 @@ def gold_train_depths():
     save("train_step_depths", **out)
 
 
+def gold_train_scenes():
+    """One training iteration (nerf.ipynb:1258-1275, the reference's pytest RNG) in the two other scene set-ups create_nerf
+    produces: forward-facing NDC rays without a white background (LLFF: ndc=True, white_bkgd=False, nerf.ipynb:952-955) and
+    Blender rays sampled linearly in disparity (lindisp=True) - the compositing backward pass without the background term
+    and the 1/z depth spacing. Losses, gradient norms and every 61st element (8x256 pair of the other fixtures)."""
+    e_fn, _ = ref_embedder.get_embedder(10, 0)
+    ed_fn, _ = ref_embedder.get_embedder(4, 0)
+    target_all = torch.from_numpy(np.random.RandomState(106).uniform(0, 1, size=(256, 3)).astype(np.float32))
+    out = dict(target=n(target_all))
+    g_ndc = np.load(os.path.join(HERE, "render_rays_ndc.npz"))
+    g_lego = np.load(os.path.join(HERE, "render_rays_lego.npz"))
+    # (256 rays for the NDC case: a single ray's resampling then moves the fine loss by 1e-6, not 1e-5)
+    for tag, rays_np, extra in (("ndc", g_ndc["rays"][:256], dict(white_bkgd=False, lindisp=False)),
+                                ("lindisp", g_lego["rays"][:32], dict(white_bkgd=True, lindisp=True))):
+        out[f"{tag}.rays"] = rays_np
+        target = target_all[:len(rays_np)]
+        # also in float64 (suffix .f64): the fine pass resamples along the coarse weights, and on the NDC rays one of 32 rays
+        # landing a sample in a neighbouring bin moves the fine loss by 1e-5 between ANY two evaluations - the reference's own
+        # fp32-vs-fp64 distance is the yardstick the test uses for the fine network
+        for sfx, dtype in (("", torch.float32), (".f64", torch.float64)):
+            old = torch.get_default_dtype()
+            torch.set_default_dtype(dtype)
+            try:
+                net_c, net_f = ref_pair(0, dtype)
+                net_c.train(); net_f.train()
+                rays = torch.from_numpy(rays_np.copy()).to(dtype)
+                kw = dict(N_samples=64, N_importance=128, retraw=True, perturb=1.0, raw_noise_std=1.0, pytest=True, **extra)
+                r = NS["render_rays"](rays, net_c, query_fn(e_fn, ed_fn), network_fine=net_f, **kw)
+                tgt = target.to(dtype)
+                img_loss, img_loss0 = ref_helpers.img2mse(r["rgb_map"], tgt), ref_helpers.img2mse(r["rgb0"], tgt)
+                (img_loss + img_loss0).backward()
+            finally:
+                torch.set_default_dtype(old)
+            out[f"{tag}.img_loss{sfx}"], out[f"{tag}.img_loss0{sfx}"] = n(img_loss), n(img_loss0)
+            for which, net in (("c", net_c), ("f", net_f)):
+                for k, p in net.named_parameters():
+                    gr = n(p.grad).reshape(-1)
+                    out[f"{tag}.gnorm_{which}.{k}{sfx}"] = np.linalg.norm(gr.astype(np.float64))
+                    out[f"{tag}.gsub_{which}.{k}{sfx}"] = gr[::61].copy()
+    save("train_step_scenes", **out)
+
+
 def gold_llff_pose_math():
     """The pure-numpy pose functions of nerf/load_llff.py, executed from its source (the module itself
     cannot be imported here: it needs imageio). Only function definitions that touch numpy alone are
@@ -802,5 +844,6 @@ if __name__ == "__main__":
     gold_widths()
     gold_train_noviewdirs()
     gold_train_depths()
+    gold_train_scenes()
     gold_llff_pose_math()
     gold_tiny_scene()

@@ -650,6 +650,46 @@ def test_train_gradients_other_depths(N, tag, seeds, arch):
             assert np.abs(gr[::61] - want_sub).max() <= 5 * tol * (np.abs(want_sub).max() + 1e-12) + 1e-9, (which, k)
 
 
+@pytest.mark.parametrize("tag,extra", [("ndc", dict(white_bkgd=False, lindisp=False)),
+                                       ("lindisp", dict(white_bkgd=True, lindisp=True))])
+def test_train_gradients_other_scenes(N, weights_pair, tag, extra):
+    """One training iteration in the two other scene set-ups create_nerf produces (nerf.ipynb:952-955): forward-facing NDC
+    rays without a white background - the compositing backward pass without its background term - and Blender rays sampled
+    linearly in disparity; against the reference's autograd (tests/golden/train_step_scenes.npz, which also holds the
+    reference's fp64 run of the same iteration), both arithmetics."""
+    g = load_golden("train_step_scenes")
+    sd_c, sd_f = weights_pair
+    net_c, net_f = make_net(N, sd_c), make_net(N, sd_f)
+    rays = g[f"{tag}.rays"]
+    kw = dict(network_fn=net_c, network_fine=net_f, N_samples=64, N_importance=128, perturb=1.0, raw_noise_std=1.0,
+              pytest=True, use_viewdirs=True, **extra)
+    opt = N.Adam([net_c, net_f], lr=5e-4)
+    # the rays are already in the form render() would pack them (NDC-warped for the LLFF case): passed through as they are
+    packed = gpu(rays)
+    out = N.train_on_batch(800, 800, None, (packed[:, 0:3], packed[:, 3:6]), gpu(g["target"][:len(rays)]), opt,
+                           apply_update=False, ndc=False, _packed_rays=packed, **kw)
+    # Bars: the usual ones, or 3x the distance between the reference's OWN fp32 and fp64 runs of this iteration where that is
+    # larger. It is larger in two places, both on the NDC rays: the fine pass resamples along the coarse weights (one ray
+    # landing a sample in a neighbouring bin moves the fine loss by 1e-6 at 256 rays), and a few coarse bias gradients are
+    # sums that cancel to 1e-3 of their terms (the reference's fp32 pts_linears.3.bias is 1e-3 from its fp64 one).
+    ref_gap = abs(float(g[f"{tag}.img_loss"]) - float(g[f"{tag}.img_loss.f64"]))
+    assert abs(float(out["img_loss0"]) - float(g[f"{tag}.img_loss0"])) <= 2e-6
+    assert abs(float(out["img_loss"]) - float(g[f"{tag}.img_loss"])) <= max(2e-6, 3 * ref_gap), ref_gap
+    for which, net in (("c", net_c), ("f", net_f)):
+        for k, gr in net.grad_dict().items():
+            gr = gr.numpy().reshape(-1)
+            want_norm, want_sub = float(g[f"{tag}.gnorm_{which}.{k}"]), g[f"{tag}.gsub_{which}.{k}"]
+            scale = np.abs(want_sub).max() + 1e-12
+            tol = 2e-5 if which == "c" else 2e-4
+            gap = np.abs(want_sub - g[f"{tag}.gsub_{which}.{k}.f64"]).max() / scale
+            gap_n = abs(want_norm - float(g[f"{tag}.gnorm_{which}.{k}.f64"])) / (want_norm + 1e-30)
+            elem, tol = max(5 * tol, 3 * gap), max(tol, 3 * gap_n)
+            d_norm = abs(np.linalg.norm(gr.astype(np.float64)) - want_norm)
+            d_elem = np.abs(gr[::61] - want_sub).max()
+            assert d_norm <= tol * want_norm + 1e-9, (which, k, d_norm / want_norm, gap_n)
+            assert d_elem <= elem * scale + 1e-9, (which, k, d_elem / scale, gap)
+
+
 def test_run_network_fused_matches_staged(N, O):
     """Fused encode+MLP == embed kernel -> cat -> MLP kernel, and both == oracle."""
     g = load_golden("mlp_forward")
