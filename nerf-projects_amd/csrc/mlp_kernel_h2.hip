@@ -788,8 +788,17 @@ struct EqualiseBatch {
     int* row_exp[2];
     float* out[2];
     EqualiseRefs refs[2];
+#ifdef NERF_ROWEXP_STAMPS      // profiles/microbench/row_exponents_bench.hip: wall_clock64() samples of thread 0 per phase
+    unsigned long long* stamps;
+#endif
 };
-__global__ __launch_bounds__(1024) void row_exponents_kernel(const EqualiseBatch batch) {
+#ifdef NERF_ROWEXP_STAMPS
+#define ROWEXP_STAMP() if (threadIdx.x == 0 && blockIdx.x == 0) batch.stamps[n_stamp++] = wall_clock64()
+#else
+#define ROWEXP_STAMP()
+#endif
+constexpr int kRowExpThreads = 1024;
+__global__ __launch_bounds__(kRowExpThreads) void row_exponents_kernel(const EqualiseBatch batch) {
     const float* params = batch.params[blockIdx.x];
     int* row_exp_out = batch.row_exp[blockIdx.x];
     const EqualiseRefs& r = batch.refs[blockIdx.x];
@@ -798,8 +807,13 @@ __global__ __launch_bounds__(1024) void row_exponents_kernel(const EqualiseBatch
     constexpr int kExpBins = 320;             // frexp exponents of finite floats lie within -148 .. 128
     __shared__ int hist[kExpBins];
     __shared__ int median_exp, n_valid;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    // (wave: known to be uniform, so that what it indexes - rows, offsets - stays in scalar registers)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = kRowExpThreads >> 6;
+#ifdef NERF_ROWEXP_STAMPS
+    int n_stamp = 0;
+#endif
     for (int idx = 0; idx < r.n; ++idx) {
+        ROWEXP_STAMP();
         const int k = r.order[idx];
         const int n_out = r.out[k], n_in = r.in[k], src = r.col_src[k], c0 = r.hid_col0[k], c1 = c0 + r.n_hid[k];
         if (r.scale_rows[k]) {
@@ -808,39 +822,73 @@ __global__ __launch_bounds__(1024) void row_exponents_kernel(const EqualiseBatch
             // sum 256) - rows of zeros with a zero bias and non-finite rows keep factor 1
             for (int q = threadIdx.x; q < kExpBins; q += blockDim.x) hist[q] = 0;
             if (threadIdx.x == 0) n_valid = 0;
-            constexpr int kRows = 8, kCols = 6;        // rows per wave and round; 64 x 6 = 384 columns cover in <= 383
+            // A wave takes kRows rows per round, a lane kCols columns of each; the rows' sums are folded together (a half
+            // of the lanes keeps one half of the rows and hands over its sums of the other: kRows - 1 exchanges of a double
+            // and log2(64 / kRows) more, not 6 kRows), and lane l ends up with row l / (64 / kRows) of the round.
+            // profiles/microbench/row_exponents_bench.hip: 9 us per 256 x 256 layer, 0.10 ms for two networks; it was 18 and
+            // 0.20 with a load behind every condition - each became a branch with its own wait - and a butterfly per row.
+            constexpr int kRows = 4, kCols = 6;        // 64 x 6 = 384 columns cover in <= 383
+            const int n_col_sets = (n_in + 63) >> 6;
+            int nec[kCols];                            // this lane's columns: minus the producer's exponent
+#pragma unroll
+            for (int t = 0; t < kCols; ++t) {
+                const int c = lane + 64 * t;
+                nec[t] = (src >= 0 && c >= c0 && c < c1) ? -expo[src][c - c0] : 0;
+            }
+            const int my_row = lane / (64 / kRows);
             for (int j0 = wave * kRows; j0 < n_out; j0 += n_waves * kRows) {
                 float v[kRows][kCols];
+                // every load unconditional, at a clamped address, zeroed afterwards
 #pragma unroll
-                for (int a = 0; a < kRows; ++a)
+                for (int t = 0; t < kCols; ++t)
+                    if (t < n_col_sets) {              // (uniform: a 256-wide layer has four column sets)
 #pragma unroll
-                    for (int t = 0; t < kCols; ++t) {
-                        const int j = j0 + a, c = lane + 64 * t;
-                        v[a][t] = (j < n_out && c < n_in) ? params[r.w_off[k] + (size_t)j * n_in + c] : 0.0f;
+                        for (int a = 0; a < kRows; ++a) {
+                            const int j = j0 + a, c = lane + 64 * t;
+                            const int jc = j < n_out ? j : n_out - 1, cc = c < n_in ? c : n_in - 1;
+                            v[a][t] = params[r.w_off[k] + (size_t)jc * n_in + cc];
+                        }
                     }
+                const int jb = j0 + my_row < n_out ? j0 + my_row : n_out - 1;
+                float bias = params[r.b_off[k] + jb];      // (with the weights, not where it is used)
+                if (j0 + my_row >= n_out) bias = 0.0f;
+                double m2[kRows];                              // (double: |w| up to FLT_MAX squares without overflow)
 #pragma unroll
-                for (int a = 0; a < kRows; ++a) {
-                    const int j = j0 + a;
-                    double m2 = 0.0;                            // (double: |w| up to FLT_MAX squares without overflow)
+                for (int a = 0; a < kRows; ++a) m2[a] = 0.0;
 #pragma unroll
-                    for (int t = 0; t < kCols; ++t) {
-                        const int c = lane + 64 * t;
-                        const int ec = (src >= 0 && c >= c0 && c < c1) ? expo[src][c - c0] : 0;
-                        const double x = (double)__builtin_ldexpf(v[a][t], -ec);
-                        m2 += x * x;
+                for (int t = 0; t < kCols; ++t)
+                    if (t < n_col_sets) {
+#pragma unroll
+                        for (int a = 0; a < kRows; ++a) {
+                            const float w = (j0 + a >= n_out || lane + 64 * t >= n_in) ? 0.0f : v[a][t];
+                            const double x = (double)__builtin_ldexpf(w, nec[t]);
+                            m2[a] = fma(x, x, m2[a]);
+                        }
                     }
-                    for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
-                    if (lane == 0 && j < n_out) {
-                        // the bias counts as a weight on a constant input: a row of zeros with a bias is a unit of size |b|
-                        const double bj = (double)params[r.b_off[k] + j];
-                        m2 += bj * bj;
-                        int ej = -1000;
-                        if (m2 > 0.0 && m2 < (double)__builtin_inff() * (double)__builtin_inff()) (void)frexp(sqrt(m2), &ej);
-                        row_exp[j] = ej;
+                int bit = 32;
+#pragma unroll
+                for (int w = kRows / 2; w >= 1; w >>= 1, bit >>= 1) {
+                    const bool up = (lane & bit) != 0;
+#pragma unroll
+                    for (int a = 0; a < w; ++a) {
+                        const double give = up ? m2[a] : m2[a + w], keep = up ? m2[a + w] : m2[a];
+                        m2[a] = keep + __shfl_xor(give, bit);
                     }
                 }
+                double m1 = m2[0];
+#pragma unroll
+                for (; bit > 0; bit >>= 1) m1 += __shfl_xor(m1, bit);
+                // the bias counts as a weight on a constant input: a row of zeros with a bias is a unit of size |b|
+                m1 = fma((double)bias, (double)bias, m1);
+                // binade of the norm sqrt(m1) from m1's own: m1 = f 2^E, f in [0.5, 1) -> ceil(E / 2)
+                int e2 = 0;
+                (void)frexp(m1, &e2);
+                const bool valid = m1 > 0.0 && m1 < (double)__builtin_inff() * (double)__builtin_inff();
+                if ((lane & (64 / kRows - 1)) == 0 && j0 + my_row < n_out) row_exp[j0 + my_row] = valid ? (e2 + 1) >> 1 : -1000;
             }
+            ROWEXP_STAMP();
             __syncthreads();
+            ROWEXP_STAMP();
             // towards the MEDIAN binade, not the largest: the ordinary units keep their scale - a skip layer concatenates
             // them with gamma(x), whose entries are not scaled, and one huge row must not push 255 others 2^20 above those
             // (a histogram over the binades a float's norm can have)
@@ -851,6 +899,7 @@ __global__ __launch_bounds__(1024) void row_exponents_kernel(const EqualiseBatch
                     atomicAdd(&n_valid, 1);
                 }
             __syncthreads();
+            ROWEXP_STAMP();
             if (wave == 0) {
                 // the smallest binade with more than half of the rows at or below it: lane l owns bins 5 l .. 5 l + 4
                 int own = 0;
@@ -873,6 +922,7 @@ __global__ __launch_bounds__(1024) void row_exponents_kernel(const EqualiseBatch
                 if (over == 0ull && lane == 0) median_exp = 0;      // (no valid row)
             }
             __syncthreads();
+            ROWEXP_STAMP();
             for (int j = threadIdx.x; j < 256; j += blockDim.x) {
                 int e = (j < n_out && row_exp[j] > -1000) ? median_exp - row_exp[j] : 0;
                 e = e > 30 ? 30 : (e < -30 ? -30 : e);      // a unit 2^30 off the median is not brought all the way
@@ -927,7 +977,7 @@ hipError_t launch_equalise_rows(int n, const float* const* params, const Equalis
         b.out[i] = params_eq[i];
         b.refs[i] = refs[i];
     }
-    hipLaunchKernelGGL(row_exponents_kernel, dim3(n), dim3(1024), 0, s, b);
+    hipLaunchKernelGGL(row_exponents_kernel, dim3(n), dim3(kRowExpThreads), 0, s, b);
     hipLaunchKernelGGL(apply_row_exponents_kernel, dim3((max_out + 3) / 4, max_n, n), dim3(256), 0, s, b);
     return hipGetLastError();
 }
