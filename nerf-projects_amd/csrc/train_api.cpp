@@ -365,7 +365,7 @@ struct TnScratch {
 // 256-workgroup rounds (a 1.5-round grid wastes a third of the machine) while keeping >= 256 points per slice.
 inline int pick_slices(int64_t P, int Mo, int No, int max_slices) {
     if (gemm_tn_is_small(Mo)) {     // [slices][Mo <= 4][No] partials: 2048 slices fit the buffers sized for 256 x 256 rows
-        const int64_t s = (P + 63) / 64;
+        const int64_t s = (P + 63) / 64;      // (measured with 128 / 256 / 512 points per slice: 48 / 55 / 88 us per launch against 42)
         return (int)(s < 1 ? 1 : (s > 2048 ? 2048 : s));
     }
     const int yb = gemm_tn_col_blocks(Mo, No);

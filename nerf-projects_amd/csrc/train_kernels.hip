@@ -481,6 +481,72 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(GemmTN g) {
         for (int m = 0; m < g.Mo; ++m) g.dbp[(int64_t)slice * g.Mo + m] = bsum[m];
 }
 
+// The same sum for No = 256 / 128 / 64 with 16-byte-aligned rows of X (what the network's own small layers are): a thread
+// takes FOUR columns, so a wave's load instruction moves a KiB instead of 256 bytes and the No / 4 threads of a point leave
+// room in the workgroup for 256 / (No / 4) points side by side (their sums are added through LDS, in order).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gemm_tn_small4_kernel(GemmTN g) {
+    __shared__ float red[4 * 1024];            // [point lane][m][column]: 256 / (No / 4) x 4 x No floats
+    __shared__ float redb[16][4];
+    const int tpp = g.No >> 2;                 // threads per point: 64, 32 or 16
+    const int pl = threadIdx.x / tpp, c = 4 * (threadIdx.x % tpp), n_pl = 256 / tpp;
+    const int slice = blockIdx.x;
+    const int64_t p_begin = (int64_t)slice * g.pts_per_slice;
+    int64_t p_end = p_begin + g.pts_per_slice;
+    if (p_end > g.P) p_end = g.P;
+    f32x4v acc[4];
+    float bsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t p = p_begin + pl;
+    const int64_t step = n_pl;
+    for (; p + 3 * step < p_end; p += 4 * step) {
+        f32x4v x[4];
+        float a[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            x[u] = *(const f32x4v*)(g.B + (p + u * step) * g.ldb + c);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[u][m] = g.A[(p + u * step) * g.lda + (m < g.Mo ? m : 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[m][q] = fmaf(a[u][m], x[u][q], acc[m][q]);
+                bsum[m] += a[u][m];
+            }
+    }
+    for (; p < p_end; p += step) {
+        const f32x4v x = *(const f32x4v*)(g.B + p * g.ldb + c);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float a = g.A[p * g.lda + (m < g.Mo ? m : 0)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[m][q] = fmaf(a, x[q], acc[m][q]);
+            bsum[m] += a;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        *(f32x4v*)&red[(pl * 4 + m) * g.No + c] = acc[m];
+        if (c == 0) redb[pl][m] = bsum[m];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < g.Mo * g.No; e += 256) {
+        const int m = e / g.No, n = e % g.No;
+        float t = red[m * g.No + n];
+        for (int q = 1; q < n_pl; ++q) t += red[(q * 4 + m) * g.No + n];
+        g.part[((int64_t)slice * g.Mo + m) * g.No + n] = t;
+    }
+    if (g.dbp && threadIdx.x < g.Mo) {
+        float t = redb[0][threadIdx.x];
+        for (int q = 1; q < n_pl; ++q) t += redb[q][threadIdx.x];
+        g.dbp[(int64_t)slice * g.Mo + threadIdx.x] = t;
+    }
+}
+
 // NERF_TRAIN_STAGED_DW=1 keeps the LDS-staged kernel for every layer (A/B and fallback)
 static bool staged_dw_requested() {
     static const bool on = [] {
@@ -539,7 +605,11 @@ hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, flo
         return hipSuccess;
     }
     if (gemm_tn_is_small(g.Mo)) {
-        hipLaunchKernelGGL(gemm_tn_small_kernel, dim3((unsigned)n_slices, (unsigned)((g.No + 255) / 256)), dim3(256), 0, s, g);
+        const bool by_four = (g.No == 256 || g.No == 128 || g.No == 64) && g.ldb % 4 == 0 && ((uintptr_t)g.B & 15) == 0;
+        if (by_four)
+            hipLaunchKernelGGL(gemm_tn_small4_kernel, dim3((unsigned)n_slices), dim3(256), 0, s, g);
+        else
+            hipLaunchKernelGGL(gemm_tn_small_kernel, dim3((unsigned)n_slices, (unsigned)((g.No + 255) / 256)), dim3(256), 0, s, g);
         const int64_t n_all = (int64_t)g.Mo * g.No + g.Mo;
         hipLaunchKernelGGL(reduce_many_slices_kernel, dim3((unsigned)((n_all + 15) / 16)), dim3(256), 0, s, g.part, g.dbp,
                            n_slices, g.Mo, g.No, dW, ldw, db, accumulate, g.ex);
