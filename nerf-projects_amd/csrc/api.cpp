@@ -759,6 +759,11 @@ int nerf_render_frame(nerf_ctx* c, const nerf_frame_args* f) {
         HIP_TRY(hipMalloc((void**)&c->frame_rays, (size_t)per * ld * sizeof(float)));
         c->frame_rays_floats = (size_t)per * ld;
     }
+    if (f->precision_guard != NERF_GUARD_OFF && f->precision_guard != NERF_GUARD_REPORT &&
+        f->precision_guard != NERF_GUARD_FALLBACK) {
+        set_error("nerf_render_frame: precision_guard %d is not a NERF_GUARD_* value", f->precision_guard);
+        return NERF_E_INVALID;
+    }
     auto body = [&]() -> int {
     for (int64_t off = 0; off < f->n_pixels; off += chunk) {
         const int64_t n = off + chunk <= f->n_pixels ? chunk : f->n_pixels - off;
@@ -792,10 +797,6 @@ int nerf_render_frame(nerf_ctx* c, const nerf_frame_args* f) {
     if (rc != NERF_OK) return rc;
     HIP_TRY(mirror_loose(c, s));
     if (f->precision_guard == NERF_GUARD_OFF || c->precision != NERF_PRECISION_F16X2) return NERF_OK;
-    if (f->precision_guard != NERF_GUARD_REPORT && f->precision_guard != NERF_GUARD_FALLBACK) {
-        set_error("nerf_render_frame: precision_guard %d is not a NERF_GUARD_* value", f->precision_guard);
-        return NERF_E_INVALID;
-    }
     // the guard: wait for the frame, look at the counter (mirrored behind the frame's kernels)
     HIP_TRY(hipStreamSynchronize(s));
     const unsigned n_new = take_new_loose(c);

@@ -2,6 +2,8 @@
 // so this file is compiled WITHOUT -amdgpu-mfma-vgpr-form (build.py), unlike the other training kernels.
 #include "nerf_internal.h"
 
+#include <cstdlib>
+
 namespace nerf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -26,6 +28,9 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // Rows: Mo must be a multiple of 128 (128 or 256); the wave row of an absent upper half exits at once.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTnDepth = 8;
+// (NT = 1 at depth 16 / 32: 123 / 130 us per launch against 128 - its four MFMAs per two points are 80 % of the fp32 pipe)
+template <int NT>
+constexpr int tn_depth() { return kTnDepth; }
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes at dword alignment (columns 63.. of a concat row)
 
 template <int NT>
@@ -88,26 +93,27 @@ void grad_batch_kernel(const GradBatch b) {
         }
     };
 
-    f32x4u ra[kTnDepth];
-    TnCols<NT> rb[kTnDepth];
+    constexpr int kDepth = tn_depth<NT>();
+    f32x4u ra[kDepth];
+    TnCols<NT> rb[kDepth];
     int s = 0;
-    if (n_steps >= kTnDepth) {
+    if (n_steps >= kDepth) {
 #pragma unroll
-        for (int j = 0; j < kTnDepth; ++j) {
+        for (int j = 0; j < kDepth; ++j) {
             ra[j] = *(const f32x4u*)pa;
             rb[j] = tn_load_cols<NT>(pb);
             pa += sa;
             pb += sb;
         }
-        for (; s + 2 * kTnDepth <= n_steps; s += kTnDepth) {
+        for (; s + 2 * kDepth <= n_steps; s += kDepth) {
 #pragma unroll
-            for (int j = 0; j < kTnDepth; ++j) {
+            for (int j = 0; j < kDepth; ++j) {
                 // pinned: the k-step's MFMAs, then its two loads and their address arithmetic - issued while the last of
                 // those MFMAs runs. Left alone hipcc hoists the loads, the bias sums and a copy of every operand register
                 // of all eight k-steps in front of the group's 128 MFMAs, ~110 instructions with an empty matrix pipe.
                 step(ra[j], rb[j]);
                 __builtin_amdgcn_sched_barrier(0);
-                ra[j] = *(const f32x4u*)pa;      // k-step s + kTnDepth + j, into the registers just consumed
+                ra[j] = *(const f32x4u*)pa;      // k-step s + kDepth + j, into the registers just consumed
                 rb[j] = tn_load_cols<NT>(pb);
                 pa += sa;
                 pb += sb;
@@ -115,8 +121,8 @@ void grad_batch_kernel(const GradBatch b) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < kTnDepth; ++j) step(ra[j], rb[j]);
-        s += kTnDepth;
+        for (int j = 0; j < kDepth; ++j) step(ra[j], rb[j]);
+        s += kDepth;
     }
     // the tail: fewer than kTnDepth whole k-steps and possibly a single last point, loads predicated per lane
     for (int64_t p = p_begin + 2 * (int64_t)s; p < p_end; p += 2) {
@@ -312,6 +318,160 @@ void grad_batch_pair_kernel(const GradBatch b) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same kernel with its operands prefetched THROUGH LDS (global_load_lds_dwordx4: no destination registers, so the
+// depth of the prefetch is no longer what the register file has left next to 256 accumulators). A wave owns kDmaSlots
+// slots of 16 KiB - the sixteen 1 KiB loads of a step, each lane's 16 bytes at lane * 16 of its load's KiB, i.e. exactly
+// what the lane reads back (no transposition, no sharing, no barrier) - and keeps kDmaSlots steps in flight: 32 KiB per
+// wave, 128 KiB per CU, twice what two register sets held. Loads return in order, so "step s has landed" is
+// vmcnt(16 x the steps issued after it).
+// ---------------------------------------------------------------------------------------------
+constexpr int kDmaSlots = 2;
+constexpr int kDmaSlotBytes = 16 * 1024;
+constexpr size_t kPairDmaLds = (size_t)4 * kDmaSlots * kDmaSlotBytes;
+
+template <int OFF>
+__device__ __forceinline__ void dma_read(f32x4u& q, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(q) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int J>
+__device__ __forceinline__ void dma_read_set(PairSet& r, unsigned addr) {
+    if constexpr (J < 8) {
+        dma_read<J * 1024>(r.a[J], addr);
+        dma_read<8192 + J * 1024>(r.b[J], addr);
+        dma_read_set<J + 1>(r, addr);
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void grad_batch_pair_dma_kernel(const GradBatch b) {
+    extern __shared__ __attribute__((aligned(16))) char dma_ring[];
+    const GradJob& g = b.job[blockIdx.y];
+    const int n_begin = g.n_begin, n_end = g.n_end, width = n_end - n_begin;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), kh = lane >> 5, i = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m_base = 128 * wm;
+    if (m_base >= g.Mo) return;                 // (no barrier anywhere below)
+    const int slice = blockIdx.x;
+    const int c_base = n_begin + 128 * wn;       // this wave's first column
+    if (c_base >= n_end) return;
+    const int col = c_base + 4 * i;
+    const int64_t p_begin = (int64_t)slice * b.pts_per_slice;
+    int64_t p_end = p_begin + b.pts_per_slice;
+    if (p_end > b.P) p_end = b.P;
+    const int64_t n_pts = p_end > p_begin ? p_end - p_begin : 0;
+    const int n_steps = (int)(n_pts / 16);
+
+    const int ea = pair_scale_exponent(g.a_max), eb = pair_scale_exponent(g.b_max);
+    const float sa = __builtin_ldexpf(1.0f, ea), sb = __builtin_ldexpf(1.0f, eb);
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
+    float asum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    const float* pa = g.A + (p_begin + 8 * kh) * g.lda + m_base + 4 * i;
+    const float* pb = g.B + (p_begin + 8 * kh) * g.ldb + col;
+    const int64_t step_a = 16 * (int64_t)g.lda, step_b = 16 * (int64_t)g.ldb;
+    char* my = dma_ring + (size_t)wave * kDmaSlots * kDmaSlotBytes;
+    const unsigned my_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)my + lane * 16;
+
+    auto issue = [&](int slot) {      // the sixteen loads of the step at (pa, pb) into `slot`
+        char* base = my + slot * kDmaSlotBytes;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + j * (int64_t)g.lda),
+                                             (__attribute__((address_space(3))) void*)(base + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + j * (int64_t)g.ldb),
+                                             (__attribute__((address_space(3))) void*)(base + 8192 + j * 1024), 16, 0, 0);
+        }
+        pa += step_a;
+        pb += step_b;
+    };
+    auto step = [&](const PairSet& r) {
+        u32x4 ahi[4], alo[4], bhi[4], blo[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float a0 = r.a[2 * q][t], a1 = r.a[2 * q + 1][t];
+                asum[t] += a0 + a1;
+                unsigned hi, lo;
+                pair_split(a0 * sa, a1 * sa, hi, lo);
+                ahi[t][q] = hi;
+                alo[t][q] = lo;
+                pair_split(r.b[2 * q][t] * sb, r.b[2 * q + 1][t] * sb, hi, lo);
+                bhi[t][q] = hi;
+                blo[t][q] = lo;
+            }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                acc[tm][tn] = mfma16h(alo[tm], bhi[tn], acc[tm][tn]);
+                acc[tm][tn] = mfma16h(ahi[tm], blo[tn], acc[tm][tn]);
+                acc[tm][tn] = mfma16h(ahi[tm], bhi[tn], acc[tm][tn]);
+            }
+    };
+
+    for (int t = 0; t < kDmaSlots && t < n_steps; ++t) issue(t);
+    int slot = 0;
+    for (int s = 0; s < n_steps; ++s) {
+        __builtin_amdgcn_sched_barrier(0);
+        // step s has landed when at most the loads of the steps issued after it are outstanding
+        if (s + 1 < n_steps) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PairSet r;
+        dma_read_set<0>(r, my_addr + slot * kDmaSlotBytes);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (read back: the slot may be overwritten)
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + kDmaSlots < n_steps) issue(slot);
+        __builtin_amdgcn_sched_barrier(0);
+        step(r);
+        slot = slot + 1 == kDmaSlots ? 0 : slot + 1;
+    }
+    // the tail: fewer than sixteen points, loads predicated per lane and point
+    const int64_t p_tail = p_begin + 16 * (int64_t)n_steps;
+    if (p_tail < p_end) {
+        PairSet r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t p = p_tail + 8 * kh + j;
+            const f32x4u z = {0.0f, 0.0f, 0.0f, 0.0f};
+            r.a[j] = z;
+            r.b[j] = z;
+            if (p < p_end) {
+                r.a[j] = *(const f32x4u*)(g.A + p * g.lda + m_base + 4 * i);
+                r.b[j] = *(const f32x4u*)(g.B + p * g.ldb + col);
+            }
+        }
+        step(r);
+    }
+
+    const float descale = __builtin_ldexpf(1.0f, -(ea + eb));
+    float* part = g.part + (int64_t)slice * g.Mo * width - n_begin;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m_base + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + tm;
+            float* dst = part + (int64_t)m * width + c_base + 4 * i;
+            const f32x4u v = {acc[tm][0][r] * descale, acc[tm][1][r] * descale, acc[tm][2][r] * descale, acc[tm][3][r] * descale};
+            *(f32x4u*)dst = v;
+        }
+    if (g.db && wn == 0) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            const float t = asum[tm] + __shfl_xor(asum[tm], 32);
+            if (kh == 0) g.dbp[(int64_t)slice * g.Mo + m_base + 4 * i + tm] = t;
+        }
+    }
+}
+
 // part[s][m][c] summed over the slices in order (deterministic) into dW[m][n_begin + c]; thread = four consecutive elements
 // of one job (eight 16-byte loads in flight), the bias gradients behind them. A job whose operands were in the units of the
 // row-equalised network scales its sums by 2^(row_exp[m] - col_exp[n]) here (GradJob): the plain parameters' gradient.
@@ -380,7 +540,23 @@ hipError_t launch_grad_batch(GradBatch& b, bool wide, float* part, size_t part_f
     }
     if (used > part_floats || used_db > dbp_floats) return hipErrorInvalidValue;
     const dim3 grid((unsigned)b.n_slices, (unsigned)b.n);
-    if (pair) hipLaunchKernelGGL(grad_batch_pair_kernel, grid, dim3(256), 0, s, b);
+    // NERF_TRAIN_DW_DMA=0 keeps the operands' prefetch in registers (A/B)
+    static const bool through_lds = [] {
+        const char* e = getenv("NERF_TRAIN_DW_DMA");
+        return !(e && *e == '0');
+    }();
+    if (pair && through_lds) {
+        static bool raised[64] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64 && !raised[dev]) {
+            e = hipFuncSetAttribute((const void*)grad_batch_pair_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPairDmaLds);
+            if (e != hipSuccess) return e;
+            raised[dev] = true;
+        }
+        hipLaunchKernelGGL(grad_batch_pair_dma_kernel, grid, dim3(256), kPairDmaLds, s, b);
+    } else if (pair) hipLaunchKernelGGL(grad_batch_pair_kernel, grid, dim3(256), 0, s, b);
     else if (wide) hipLaunchKernelGGL(grad_batch_kernel<4>, grid, dim3(256), 0, s, b);
     else hipLaunchKernelGGL(grad_batch_kernel<1>, grid, dim3(256), 0, s, b);
     hipLaunchKernelGGL(grad_batch_reduce_kernel, dim3((unsigned)((max_threads + 255) / 256), (unsigned)b.n), dim3(256), 0, s, b);
