@@ -329,6 +329,13 @@ struct GradJob {
     // index inside the Linear's input, scaled only inside [col_lo, col_hi): the hidden part of a concatenated input);
     // nullptr = 0.
     GradExps ex;
+    // (last, so that the positional initialisers of the other jobs leave them zero) grad_batch_pair_dma_kernel only: a ONE-ROW
+    // Linear on the same input X - alpha_linear beside feature_linear (nerf.py:86,89) - rides along: y [P] (stride ldy) is its
+    // dY, and its weight gradient sum_p y[p] X[p, :] is formed in fp32 from the X values the job has in registers anyway (a
+    // kernel of its own read X a second time). y_part [n_slices][n_end - n_begin], y_dbp [n_slices].
+    const float* y; int ldy;
+    float* y_part;
+    float* y_dbp;
 };
 constexpr int kMaxGradJobs = 12;
 // points per slice are a multiple of this: whole 32-point tiles for the staged kernel, whole groups of k-steps (two points each,
@@ -343,6 +350,15 @@ struct GradBatch {
 // pair: the wide jobs on the fp16 matrix pipe (every job needs a_max / b_max)
 hipError_t launch_grad_batch(GradBatch& b, bool wide, float* part, size_t part_floats, float* dbp, size_t dbp_floats,
                              hipStream_t s, bool pair = false);
+// a rider row (GradJob::y) needs the LDS-prefetch kernel; its sums are added up into (dW_row [n_end - n_begin], db_row)
+struct GradRider {
+    int job;               // index in the batch
+    float* dW; float* db;
+    GradExps ex;
+};
+bool grad_pair_takes_riders();
+hipError_t launch_grad_batch_with_rider(GradBatch& b, const GradRider& r, float* part, size_t part_floats, float* dbp,
+                                        size_t dbp_floats, hipStream_t s);
 hipError_t launch_embed_train(const float* rays, int ray_ld, const float* z, int64_t P, int S, int Lx, int Lv,
                               float* x0, int ld0, float* x1, int ld1, float* vcat, int ldv, int voff, hipStream_t s);
 hipError_t launch_mse(const float* x, const float* t, int64_t n, float* grad, double* part, float* loss, hipStream_t s);

@@ -478,9 +478,17 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     const int hl_ld = ps.h_ld[a.D - 1];
     int rc;
     if ((rc = grad_linear(net, rgb, ps.d_raw, ps.C, ps.hv, views.out, ps.P, sc, s, eq))) return rc;
-    if ((rc = grad_linear(net, alpha, ps.d_raw + 3, ps.C, hl, hl_ld, ps.P, sc, s, eq))) return rc;
     const bool batched = gemm_tn_is_direct(a.W) && gemm_tn_is_direct(views.out) && a.input_ch <= 64 &&
                          a.input_ch_views <= 64 && a.D + 1 <= kMaxGradJobs;
+    // alpha_linear reads what feature_linear reads (h_{D-1}, nerf.py:86,89): its one-row gradient rides in that job of the
+    // fp16-pair batch (GradJob::y) where the kernel that takes riders is in use; a launch of its own otherwise
+    static const bool rider_wanted = [] {      // NERF_TRAIN_DW_RIDER=0: A/B
+        const char* e = getenv("NERF_TRAIN_DW_RIDER");
+        return !(e && *e == '0');
+    }();
+    const bool alpha_rides = rider_wanted && batched && pair_dw && grad_pair_takes_riders() && a.D + 2 <= kMaxGradJobs &&
+                             hl_ld % 4 == 0;
+    if (!alpha_rides && (rc = grad_linear(net, alpha, ps.d_raw + 3, ps.C, hl, hl_ld, ps.P, sc, s, eq))) return rc;
     if (!batched) {
         if ((rc = grad_linear(net, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, ps.P, sc, s, eq))) return rc;
         if ((rc = grad_linear(net, feat, d_feat, a.W, hl, hl_ld, ps.P, sc, s, eq))) return rc;
@@ -529,7 +537,14 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
         b->P = ps.P;
         b->accumulate = sc.accumulate;
         TrainTimer timer(ps.ctx, s, b == &narrow ? 3 : 2, ps.P);
-        HIP_TRY(launch_grad_batch(*b, b != &narrow, sc.part, sc.part_floats, sc.dbp, sc.dbp_floats, s, b == &pairs));
+        if (b == &pairs && alpha_rides) {      // (job 0 of the batch is feature_linear's)
+            b->job[0].y = ps.d_raw + 3;
+            b->job[0].ldy = ps.C;
+            const GradRider rider{0, grad + alpha.w_off, grad + alpha.b_off, grad_exps(net, a.D + 2, eq)};
+            HIP_TRY(launch_grad_batch_with_rider(*b, rider, sc.part, sc.part_floats, sc.dbp, sc.dbp_floats, s));
+        } else {
+            HIP_TRY(launch_grad_batch(*b, b != &narrow, sc.part, sc.part_floats, sc.dbp, sc.dbp_floats, s, b == &pairs));
+        }
     }
     return NERF_OK;
 }

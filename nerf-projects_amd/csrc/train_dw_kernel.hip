@@ -327,7 +327,8 @@ void grad_batch_pair_kernel(const GradBatch b) {
 // vmcnt(16 x the steps issued after it).
 // ---------------------------------------------------------------------------------------------
 constexpr int kDmaSlots = 2;
-constexpr int kDmaSlotBytes = 16 * 1024;
+constexpr int kDmaRiderOff = 16 * 1024;        // behind a step's sixteen KiB: its sixteen y values (GradJob::y), one 256-byte load
+constexpr int kDmaSlotBytes = 16 * 1024 + 256;
 constexpr size_t kPairDmaLds = (size_t)4 * kDmaSlots * kDmaSlotBytes;
 
 template <int OFF>
@@ -373,12 +374,18 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
     float asum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // the rider row (GradJob::y): the waves of the first row half hold X of their 128 columns anyway
+    const bool has_y = g.y != nullptr && wm == 0;      // (wave-uniform)
+    float ysum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ybias = 0.0f;
+    const float* py = has_y ? g.y + (p_begin + (lane & 15)) * g.ldy : nullptr;
+    const int64_t step_y = 16 * (int64_t)g.ldy;
 
     const float* pa = g.A + (p_begin + 8 * kh) * g.lda + m_base + 4 * i;
     const float* pb = g.B + (p_begin + 8 * kh) * g.ldb + col;
     const int64_t step_a = 16 * (int64_t)g.lda, step_b = 16 * (int64_t)g.ldb;
     char* my = dma_ring + (size_t)wave * kDmaSlots * kDmaSlotBytes;
-    const unsigned my_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)my + lane * 16;
+    const unsigned my_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)my;
+    const unsigned my_addr = my_lds + lane * 16;
 
     auto issue = [&](int slot) {      // the sixteen loads of the step at (pa, pb) into `slot`
         char* base = my + slot * kDmaSlotBytes;
@@ -389,8 +396,27 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + j * (int64_t)g.ldb),
                                              (__attribute__((address_space(3))) void*)(base + 8192 + j * 1024), 16, 0, 0);
         }
+        if (has_y) {      // lane l fetches y of point (l & 15) of the step: LDS [16 floats] x 4 copies
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)py,
+                                             (__attribute__((address_space(3))) void*)(base + kDmaRiderOff), 4, 0, 0);
+            py += step_y;
+        }
         pa += step_a;
         pb += step_b;
+    };
+    auto ride = [&](const PairSet& r, const f32x4u& y0, const f32x4u& y1) {      // y of this lane's eight points
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 s01 = {ysum[0], ysum[1]}, s23 = {ysum[2], ysum[3]};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float yj = j < 4 ? y0[j] : y1[j - 4];
+            const f32x2 yy = {yj, yj};
+            // (v_pk_fma_f32: two columns per instruction)
+            s01 = __builtin_elementwise_fma(yy, f32x2{r.b[j][0], r.b[j][1]}, s01);
+            s23 = __builtin_elementwise_fma(yy, f32x2{r.b[j][2], r.b[j][3]}, s23);
+            ybias += yj;
+        }
+        ysum[0] = s01[0]; ysum[1] = s01[1]; ysum[2] = s23[0]; ysum[3] = s23[1];
     };
     auto step = [&](const PairSet& r) {
         u32x4 ahi[4], alo[4], bhi[4], blo[4];
@@ -423,14 +449,22 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
     for (int s = 0; s < n_steps; ++s) {
         __builtin_amdgcn_sched_barrier(0);
         // step s has landed when at most the loads of the steps issued after it are outstanding
-        if (s + 1 < n_steps) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (s + 1 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (has_y) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");      // (a step of a wave with the rider is 17 loads)
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         PairSet r;
+        f32x4u y0 = {0.0f, 0.0f, 0.0f, 0.0f}, y1 = y0;
         dma_read_set<0>(r, my_addr + slot * kDmaSlotBytes);
+        if (has_y) {
+            const unsigned ya = my_lds + slot * kDmaSlotBytes + kh * 32;
+            dma_read<kDmaRiderOff>(y0, ya);
+            dma_read<kDmaRiderOff + 16>(y1, ya);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (read back: the slot may be overwritten)
         __builtin_amdgcn_sched_barrier(0);
         if (s + kDmaSlots < n_steps) issue(slot);
         __builtin_amdgcn_sched_barrier(0);
+        if (has_y) ride(r, y0, y1);
         step(r);
         slot = slot + 1 == kDmaSlots ? 0 : slot + 1;
     }
@@ -448,6 +482,17 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
                 r.a[j] = *(const f32x4u*)(g.A + p * g.lda + m_base + 4 * i);
                 r.b[j] = *(const f32x4u*)(g.B + p * g.ldb + col);
             }
+        }
+        if (has_y) {
+            f32x4u y0 = {0.0f, 0.0f, 0.0f, 0.0f}, y1 = y0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t p = p_tail + 8 * kh + j;
+                const float v = p < p_end ? g.y[p * g.ldy] : 0.0f;
+                if (j < 4) y0[j] = v;
+                else y1[j - 4] = v;
+            }
+            ride(r, y0, y1);
         }
         step(r);
     }
@@ -469,6 +514,14 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
             const float t = asum[tm] + __shfl_xor(asum[tm], 32);
             if (kh == 0) g.dbp[(int64_t)slice * g.Mo + m_base + 4 * i + tm] = t;
         }
+    }
+    if (has_y) {      // the two half-waves hold the two halves of every step's points
+        f32x4u v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = ysum[t] + __shfl_xor(ysum[t], 32);
+        if (kh == 0) *(f32x4u*)(g.y_part + (int64_t)slice * width + (c_base - n_begin) + 4 * i) = v;
+        const float tb = ybias + __shfl_xor(ybias, 32);
+        if (wn == 0 && lane == 0) g.y_dbp[slice] = tb;
     }
 }
 
@@ -520,10 +573,32 @@ __global__ __launch_bounds__(256) void grad_batch_reduce_kernel(const GradBatch 
     }
 }
 
+bool grad_pair_takes_riders() {      // NERF_TRAIN_DW_DMA=0 keeps the operands' prefetch in registers (A/B; that kernel takes no rider)
+    static const bool through_lds = [] {
+        const char* e = getenv("NERF_TRAIN_DW_DMA");
+        return !(e && *e == '0');
+    }();
+    return through_lds;
+}
+
+static hipError_t launch_grad_batch_impl(GradBatch& b, bool wide, float* part, size_t part_floats, float* dbp, size_t dbp_floats,
+                                         hipStream_t s, bool pair, const GradRider* rider);
+
 hipError_t launch_grad_batch(GradBatch& b, bool wide, float* part, size_t part_floats, float* dbp, size_t dbp_floats,
                              hipStream_t s, bool pair) {
+    return launch_grad_batch_impl(b, wide, part, part_floats, dbp, dbp_floats, s, pair, nullptr);
+}
+hipError_t launch_grad_batch_with_rider(GradBatch& b, const GradRider& r, float* part, size_t part_floats, float* dbp,
+                                        size_t dbp_floats, hipStream_t s) {
+    return launch_grad_batch_impl(b, true, part, part_floats, dbp, dbp_floats, s, true, &r);
+}
+
+static hipError_t launch_grad_batch_impl(GradBatch& b, bool wide, float* part, size_t part_floats, float* dbp, size_t dbp_floats,
+                             hipStream_t s, bool pair, const GradRider* rider) {
     if (b.n <= 0) return hipSuccess;
     if (b.n > kMaxGradJobs || b.n_slices <= 0) return hipErrorInvalidValue;
+    if (rider && (!grad_pair_takes_riders() || rider->job < 0 || rider->job >= b.n || b.n >= kMaxGradJobs || !b.job[rider->job].y))
+        return hipErrorInvalidValue;
     size_t used = 0, used_db = 0;
     int64_t max_threads = 0;
     for (int j = 0; j < b.n; ++j) {
@@ -538,14 +613,29 @@ hipError_t launch_grad_batch(GradBatch& b, bool wide, float* part, size_t part_f
         const int64_t th = ((int64_t)g.Mo * width + 3) / 4 + g.Mo;
         max_threads = th > max_threads ? th : max_threads;
     }
+    int n_all = b.n;
+    if (rider) {      // the rider's partial sums, and a reduce-only entry behind the real jobs that adds them up
+        GradJob& g = b.job[rider->job];
+        const int width = g.n_end - g.n_begin;
+        g.y_part = part + used;
+        used += (size_t)b.n_slices * width;
+        g.y_dbp = dbp + used_db;
+        used_db += (size_t)b.n_slices;
+        GradJob& x = b.job[n_all++];
+        x = GradJob{};
+        x.Mo = 1;
+        x.n_begin = 0;
+        x.n_end = width;
+        x.dW = rider->dW;
+        x.ldw = width;
+        x.db = rider->db;
+        x.part = g.y_part;
+        x.dbp = g.y_dbp;
+        x.ex = rider->ex;
+    }
     if (used > part_floats || used_db > dbp_floats) return hipErrorInvalidValue;
     const dim3 grid((unsigned)b.n_slices, (unsigned)b.n);
-    // NERF_TRAIN_DW_DMA=0 keeps the operands' prefetch in registers (A/B)
-    static const bool through_lds = [] {
-        const char* e = getenv("NERF_TRAIN_DW_DMA");
-        return !(e && *e == '0');
-    }();
-    if (pair && through_lds) {
+    if (pair && grad_pair_takes_riders()) {
         static bool raised[64] = {};
         int dev = 0;
         hipError_t e = hipGetDevice(&dev);
@@ -559,7 +649,7 @@ hipError_t launch_grad_batch(GradBatch& b, bool wide, float* part, size_t part_f
     } else if (pair) hipLaunchKernelGGL(grad_batch_pair_kernel, grid, dim3(256), 0, s, b);
     else if (wide) hipLaunchKernelGGL(grad_batch_kernel<4>, grid, dim3(256), 0, s, b);
     else hipLaunchKernelGGL(grad_batch_kernel<1>, grid, dim3(256), 0, s, b);
-    hipLaunchKernelGGL(grad_batch_reduce_kernel, dim3((unsigned)((max_threads + 255) / 256), (unsigned)b.n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(grad_batch_reduce_kernel, dim3((unsigned)((max_threads + 255) / 256), (unsigned)n_all), dim3(256), 0, s, b);
     return hipGetLastError();
 }
 
