@@ -54,3 +54,29 @@ def test_no_register_touched_before_its_lds_wait(src, tmp_path):
         body = text[text.index(inst):]
         body = body[:body.index("s_endpgm")]
         assert "scratch_" not in body, inst
+
+
+def test_weight_gradient_kernel_prefetched_through_lds(tmp_path):
+    """grad_batch_pair_dma_kernel (train_dw_kernel.hip) keeps two steps of operands in flight as LDS-DMA loads and reads them
+    back from inline asm behind hand-counted waits: the same audit (no register of a read back touched before its wait, no
+    scalar hazard), no scratch (a reload would go through the vector-memory counter the prefetch owns), and the only counted
+    vector-memory waits in the generated code are the ones the source states - 16 loads of a step, 17 with the rider row, 0."""
+    import re
+    build = _load(os.path.join(PKG, "build.py"), "nerf_build_for_audit")
+    audit = _load(os.path.join(ROOT, "tools", "audit_lds_waits.py"), "audit_lds_waits")
+    src, inst = "train_dw_kernel.hip", "grad_batch_pair_dma_kernel"
+    out = tmp_path / (src + ".s")
+    cmd = [build.hipcc()] + build.FLAGS + build.EXTRA.get(src, build.VGPR_FORM) + \
+        ["-I", os.path.join(ROOT, "include"), "-I", build.CSRC, "--cuda-device-only", "-S",
+         os.path.join(build.CSRC, src), "-o", str(out)]
+    subprocess.run(cmd, check=True, cwd=tmp_path)
+    findings, n_ops, n_waits = audit.audit(str(out), inst)
+    assert n_ops > 60 and n_waits > 20, (n_ops, n_waits)
+    assert not findings, findings[:5]
+    assert not audit.audit_sgpr_hazards(str(out), inst)
+    text = open(out).read()
+    body = text[text.index(inst):]
+    body = body[:body.index("s_endpgm")]
+    assert "scratch_" not in body
+    assert body.count("global_load_lds_dwordx4") >= 32 and body.count("global_load_lds_dword ") >= 1
+    assert set(re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)) == {"0", "16", "17"}
