@@ -1002,6 +1002,25 @@ def test_frame_as_eight_shards_is_bit_identical(N, nets, workload):
         N.render_shard(H, W, K, 8, 0, **cam, **dict(kw, perturb=1.0))
 
 
+def test_rays_do_not_see_their_neighbours(N, nets):
+    """A size-independent property at the bench frame's size: a ray's result is a function of that ray alone
+    (nerf.ipynb:359-492 has no term across rays), so the 640 000 rays of the 800 x 800 frame in a random order come back with
+    bit-identical values in that order - whichever 32-point tile, wavefront, workgroup and chunk a ray lands in, with both
+    arithmetics (the fp16-pair kernel's scales are per point, its weight scales per layer)."""
+    net_c, net_f, q = nets
+    H, W = 800, 800
+    K, c2w, near, far = synthetic.lego_camera(H, W)
+    rays = N.generate_rays(H, W, K, c2w, ndc=False, near=near, far=far, use_viewdirs=True)
+    kw = dict(network_fn=net_c, network_fine=net_f, network_query_fn=q, N_samples=64, N_importance=128,
+              white_bkgd=True, perturb=0., raw_noise_std=0.)
+    whole = N.batchify_rays(rays, 32768, **kw)
+    perm = torch.randperm(rays.shape[0], generator=torch.Generator().manual_seed(11)).to(rays.device)
+    mixed = N.batchify_rays(rays[perm].contiguous(), 32768, **kw)
+    for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"):
+        assert torch.equal(mixed[k], whole[k][perm]), k
+    assert torch.isfinite(whole["rgb_map"]).all()
+
+
 def test_nonfinite_inputs_propagate_like_the_reference(N, O, nets):
     """F.relu propagates NaN (nerf/nerf.py:72) and v_max_f32 does not; the kernels restore the reference's result for
     non-finite INPUTS: a NaN / Inf position makes all four channels of the point NaN, a NaN / Inf direction its colour
