@@ -385,12 +385,12 @@ __global__ __launch_bounds__(1024) void layer_gain_bwd_kernel(const float* param
     for (int c0 = q * per; c0 < (q + 1) * per; c0 += 8) {      // eight loads in flight
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 8; ++u) {      // (unconditional, at a clamped row: behind a condition each load is a branch with its own wait)
             const int c = c0 + u;
-            v[u] = (c < (q + 1) * per && c < n_rows) ? w[(size_t)c * refs.ld[l]] : 0.0f;
+            v[u] = w[(size_t)(c < n_rows ? c : n_rows - 1) * refs.ld[l]];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) sum += fabsf(v[u]);
+        for (int u = 0; u < 8; ++u) sum += (c0 + u < (q + 1) * per && c0 + u < n_rows) ? fabsf(v[u]) : 0.0f;
     }
     part[q][r] = sum;
     __syncthreads();
