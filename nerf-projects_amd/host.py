@@ -470,7 +470,8 @@ def _noise(shape, raw_noise_std, pytest, ctx):
     if pytest:
         np.random.seed(0)
         return _dev(np.random.rand(*shape) * noise_std, ctx)
-    return torch.randn(shape, device=ctx.device, dtype=torch.float32) * noise_std
+    noise = torch.randn(shape, device=ctx.device, dtype=torch.float32)
+    return noise if noise_std == 1.0 else noise * noise_std      # (every YAML of the reference has raw_noise_std 1e0: x * 1 = x)
 
 
 def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False):
@@ -778,10 +779,10 @@ def pack_rays(H, W, K, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewd
         rays_o, rays_d = ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
     rays_o = torch.reshape(rays_o, [-1, 3]).float()
     rays_d = torch.reshape(rays_d, [-1, 3]).float()
-    near_c, far_c = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
-    packed = torch.cat([rays_o, rays_d, near_c, far_c], -1)
-    if use_viewdirs:
-        packed = torch.cat([packed, viewdirs], -1)
+    # near * ones_like(...), far * ones_like(...), two cats (nerf.ipynb:622-629): the same values in three launches less
+    near_c = torch.full_like(rays_d[..., :1], float(near))
+    far_c = torch.full_like(rays_d[..., :1], float(far))
+    packed = torch.cat([rays_o, rays_d, near_c, far_c] + ([viewdirs] if use_viewdirs else []), -1)
     return packed, sh
 
 
@@ -1186,9 +1187,10 @@ def train_on_batch(H, W, K, batch_rays, target_s, optimizer, chunk=1024 * 32, nd
     a.loss, a.rgb_map, a.rgb0 = loss.data_ptr(), rgb.data_ptr(), (rgb0.data_ptr() if Si > 0 else None)
     a.stream = ctx.stream().value
     check(ctx.lib.nerf_train_step(ctx.handle, C.byref(a)))
-    out = {'img_loss': loss[0], 'psnr': mse2psnr(loss[0]), 'rgb': rgb, 'loss': loss[0]}
+    psnr = mse2psnr(loss)      # (both at once: element-wise, the same values as one call per loss)
+    out = {'img_loss': loss[0], 'psnr': psnr[0], 'rgb': rgb, 'loss': loss[0]}
     if Si > 0:
-        out.update(img_loss0=loss[1], psnr0=mse2psnr(loss[1]), rgb0=rgb0, loss=loss[0] + loss[1])
+        out.update(img_loss0=loss[1], psnr0=psnr[1], rgb0=rgb0, loss=loss[0] + loss[1])
     return out
 
 
