@@ -306,6 +306,10 @@ def pmc_traffic(precision):
 
 
 def main():
+    # dmabuf IPC between the ranks of one node: this pool's host driver supports nothing else, and HSA reads the variable when
+    # the first GPU call initialises it - so it is set here, before torch.cuda.set_device, in BOTH launch forms (the image
+    # exports it already; a launcher that scrubs the environment must not be able to undo that)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -352,11 +356,20 @@ def main():
         ctx.set_precision(args.precision)
     precision = ctx.get_precision()
 
+    gather_events = []      # (start, end) around every frame's gather on this rank's stream (N > 1 only)
+
     def step():
         ret = N.batchify_rays(shard, args.chunk, **kw)
         local_out = {k: ret[k] for k in ("rgb_map", "disp_map", "acc_map")}
         if use_dist:
-            return N.gather_frame(local_out, n_total, force_collective=True)
+            # the collective runs on RCCL's own stream, which torch orders after `e0` and makes the current stream wait for
+            # before `e1`: the pair brackets packing + wire time + (on the other ranks) the wait for the slowest shard
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = N.gather_frame(local_out, n_total, force_collective=True)
+            e1.record()
+            gather_events.append((e0, e1))
+            return out
         return local_out
 
     def fence():
@@ -373,6 +386,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    gather_events.clear()
     ctx.profile_enable(True)
     ctx.profile_read(reset=True)
     t0 = time.perf_counter()
@@ -383,10 +397,21 @@ def main():
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
     mlp_ms, mlp_launches, mlp_points = ctx.profile_read(reset=True)
+    gather_ms = sum(a.elapsed_time(b) for a, b in gather_events) / max(len(gather_events), 1)
     t = torch.tensor([dt, mlp_ms, float(mlp_points), float(mlp_launches)], device="cuda", dtype=torch.float64)
+    per_rank = None
     if use_dist:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # one line must be enough to read a scaling record: every rank's own clock, kernel time and gather time
+        mine = torch.tensor([dt / args.steps * 1e3, mlp_ms / args.steps, gather_ms, float(hi - lo)], device="cuda",
+                            dtype=torch.float64)
+        rows = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+        per_rank = {"ms_per_step": [round(float(r[0]), 3) for r in rows],
+                    "mlp_kernel_ms_per_step": [round(float(r[1]), 3) for r in rows],
+                    "gather_ms": [round(float(r[2]), 3) for r in rows],
+                    "rays": [int(r[3]) for r in rows]}
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt = float(tmax[0])
         mlp_ms_sum, pts_sum, launches_sum = float(t[1]), float(t[2]), float(t[3])
@@ -466,6 +491,12 @@ def main():
                          "avg_launch_ms": avg_launch_s * 1e3, "flop_per_launch": flop_per_launch,
                          "kernel_time_share": mlp_ms_sum * 1e-3 / world / dt},
         }
+        if per_rank is not None:
+            # gather_ms: HIP events around gather_frame on each rank (rank 0's is the collective as the root sees it; the
+            # others' include waiting for the root); ms_per_step: each rank's own wall clock over the timed steps
+            out["per_rank"] = per_rank
+            out["gather_ms"] = per_rank["gather_ms"][0]
+            out["hsa_enable_ipc_mode_legacy"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
         if other is not None:
             out["other_precision"] = other
         out["precision_status"] = int(ctx.precision_status())      # layers whose a-priori scale bound was loose (0 = none)

@@ -12,7 +12,7 @@ from .host import (Adam, NeRF, NetworkQuery, train_on_batch, batchify, batchify_
                    render, render_path, render_rays, render_shard, run_network, sample_pdf, save_checkpoint, to8b, write_png)
 from . import datasets  # noqa: F401
 from .datasets import load_blender_data, load_llff_data, read_png  # noqa: F401
-from .sharded import gather_frame, render_sharded, shard_bounds  # noqa: F401
+from .sharded import ensure_ipc_env, gather_frame, render_sharded, shard_bounds  # noqa: F401
 from .batching import RayBatcher  # noqa: F401
 
 __version__ = "0.1.0"

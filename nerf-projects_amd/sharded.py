@@ -7,9 +7,26 @@ rank (one process per GPU, ``torch.distributed`` with the ``nccl`` = RCCL backen
 xGMI) renders its shard with no data-path collective, and the only exchange is a gather
 of ``rgb|disp|acc`` (20 B/ray, 1.6 MB per GPU for an 800x800 frame) to rank 0.
 Weights (4.8 MB) are loaded by every rank from the same state dict.
+
+RCCL between the processes of one node shares device buffers by IPC handles; the host driver of the MI355X pool this
+was built on supports only the dmabuf form, which HSA selects when ``HSA_ENABLE_IPC_MODE_LEGACY=0`` is in the environment
+at the first GPU call of the process. ``ensure_ipc_env()`` puts it there (never overriding a value the user set); it runs
+when this module is imported - importing the package does not touch the GPU - so library users get the same environment
+as ``bench.py`` in either launch form.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def ensure_ipc_env():
+    """``HSA_ENABLE_IPC_MODE_LEGACY=0`` unless the caller chose a value. Must precede the process's first GPU call to have
+    any effect (HSA reads it once); returns the value in force."""
+    return os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+ensure_ipc_env()
 
 
 def shard_bounds(n, world_size, rank):

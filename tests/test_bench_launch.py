@@ -77,3 +77,57 @@ def test_self_launch_relays_output_and_exit_code(bench, monkeypatch, capfd):
     rc = bench.self_launch(argparse.Namespace(gpus=2))
     out = capfd.readouterr().out
     assert rc == 5 and '{"metric": 1}' in out
+
+
+@pytest.mark.parametrize("world", ["8", "1"])
+def test_launcher_form_sets_the_ipc_mode_before_any_gpu_call(bench, monkeypatch, world):
+    """Under `python -m torch.distributed.run ... bench.py --gpus 8` (WORLD_SIZE / RANK / LOCAL_RANK in the environment,
+    no self-launch hop) main() must have HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment when torch.cuda.set_device - the
+    process's first GPU call, where HSA reads it - runs; a value chosen by the user is kept."""
+    import torch
+
+    class Reached(Exception):
+        pass
+
+    seen = {}
+
+    def first_gpu_call(*a, **k):
+        seen["value"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+        raise Reached()
+
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    monkeypatch.setenv("WORLD_SIZE", world)
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setattr(bench, "self_launch", lambda args: pytest.fail("hopped under the launcher"))
+    monkeypatch.setattr(torch.cuda, "set_device", first_gpu_call)
+    monkeypatch.setattr(torch.distributed, "init_process_group",
+                        lambda *a, **k: pytest.fail("process group before the device was selected"))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", world])
+    with pytest.raises(Reached):
+        bench.main()
+    assert seen["value"] == "0"
+    # the user's own choice survives
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
+    with pytest.raises(Reached):
+        bench.main()
+    assert seen["value"] == "1"
+
+
+def test_self_launch_child_environment_carries_it_too(bench, monkeypatch, capfd):
+    import argparse
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    monkeypatch.setattr(bench, "self_launch_command", lambda argv, n, port=None: [
+        sys.executable, "-c", "import os; print(os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'), os.environ.get('NERF_BENCH_SELF_LAUNCHED'))"])
+    assert bench.self_launch(argparse.Namespace(gpus=2)) == 0
+    assert capfd.readouterr().out.split() == ["0", "1"]
+
+
+def test_package_import_sets_it_for_library_users(monkeypatch):
+    """sharded.ensure_ipc_env: what `import nerf_projects_amd` leaves in the environment (never overriding)."""
+    sys.path.insert(0, ROOT)
+    import nerf_projects_amd as N
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    assert N.ensure_ipc_env() == "0" and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
+    assert N.ensure_ipc_env() == "1"
