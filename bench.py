@@ -153,7 +153,8 @@ def cpu_baseline(sample_rays, sd_c, sd_f, Sc, Si, white, target_s):
             tried[t] = rate(probe)
         best = max(tried, key=tried.get)
         torch.set_num_threads(best)
-        n = int(min(len(sample_rays), max(256, target_s * tried[best] / evals_per_ray)))
+        # (half of the budget for this single-pool sample, half for the whole-host leg below)
+        n = int(min(len(sample_rays), max(256, 0.5 * target_s * tried[best] / evals_per_ray)))
         n = max(64, (n // 64) * 64)
         t0 = time.perf_counter()
         O.batchify_rays(sample_rays[:n], 1024, network_fn=net_c, network_query_fn=q, **kw)
@@ -162,8 +163,9 @@ def cpu_baseline(sample_rays, sd_c, sd_f, Sc, Si, white, target_s):
         torch.set_num_threads(old_threads)
         O.set_gemm_backend("numpy")
     evals = n * evals_per_ray
+    whole = cpu_baseline_all_cores(sample_rays, Sc, Si, white, best, ncpu, evals / dt, 0.5 * target_s)
     return {"value": evals / dt, "unit": "ray-samples/s", "cores": int(best), "kind": "port",
-            "per_core": evals / dt / best,
+            "per_core": evals / dt / best, **whole,
             "threads_tried": {str(k): round(v) for k, v in tried.items()},
             "numpy_openblas_backend": round(t_numpy),
             "reference_pytorch_cpu_survey_container": "0.96e5-1.24e5 ray-samples/s on 8 threads (BASELINE.md section 2; other host)",
@@ -172,6 +174,64 @@ def cpu_baseline(sample_rays, sd_c, sd_f, Sc, Si, white, target_s):
                       f"of the host ({ncpu} logical cores usable), {n / dt:.0f} rays/s, {evals / dt / best:.0f} "
                       f"ray-samples/s/core; numpy/OpenBLAS backend on the probe: {t_numpy:.0f} ray-samples/s; the "
                       f"reference's own PyTorch-CPU path measured in the survey container: 0.96e5-1.24e5 on 8 threads"}
+
+
+def cpu_baseline_all_cores(sample_rays, Sc, Si, white, threads, ncpu, single_pool_rate, target_s):
+    """The node's host cores all at once (north_star: "timed on the node's own host cores"): one BLAS thread pool stops
+    scaling at `threads` threads (threads_tried), so P = ncpu // threads worker PROCESSES (oracle/cpu_worker.py: fresh
+    children, GPU hidden from them, `threads` threads each) render disjoint slices of the same sample side by side, started
+    together; the rate is all their ray-samples over the time until the last one has finished."""
+    import subprocess
+    import tempfile
+    procs = max(1, ncpu // max(threads, 1))
+    evals_per_ray = Sc + (Sc + Si if Si else 0)
+    if procs < 2:
+        return {"value_all_cores": single_pool_rate, "processes": 1, "threads_per_process": int(threads),
+                "all_cores_note": "one process already uses every usable core"}
+    # side by side the processes share memory bandwidth: assume 60 % of the single-pool rate each when sizing the slices
+    n_each = int(max(64, min(len(sample_rays) // procs, target_s * 0.6 * single_pool_rate / evals_per_ray)))
+    n_each = max(64, n_each // 64 * 64)
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="",
+               PYTHONDONTWRITEBYTECODE="1")
+    workers, files = [], []
+    try:
+        for p in range(procs):
+            f = tempfile.NamedTemporaryFile(suffix=".npy", delete=False)
+            f.close()
+            np.save(f.name, np.ascontiguousarray(sample_rays[p * n_each:(p + 1) * n_each]))
+            files.append(f.name)
+            workers.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), str(threads),
+                                             f.name, str(Sc), str(Si), str(int(bool(white)))], env=env, stdin=subprocess.PIPE,
+                                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+        for w in workers:
+            if w.stdout.readline().strip() != "ready":
+                raise RuntimeError("a CPU worker did not come up")
+        t0 = time.perf_counter()
+        for w in workers:
+            w.stdin.write("go\n")
+            w.stdin.flush()
+        results = [json.loads(w.stdout.readline()) for w in workers]
+        wall = time.perf_counter() - t0
+        for w in workers:
+            w.wait(timeout=30)
+    except Exception as e:                      # reported, never fatal for the GPU line
+        for w in workers:
+            if w.poll() is None:
+                w.kill()
+        return {"value_all_cores": None, "processes": procs, "threads_per_process": int(threads),
+                "all_cores_note": f"failed: {type(e).__name__}: {e}"}
+    finally:
+        for name in files:
+            try:
+                os.unlink(name)
+            except OSError:
+                pass
+    total = sum(r["rays"] for r in results) * evals_per_ray
+    return {"value_all_cores": total / wall, "processes": procs, "threads_per_process": int(threads),
+            "cores_all": procs * int(threads),
+            "all_cores_note": f"{procs} processes x {threads} threads, {n_each} rays each, started together: {total} MLP evals "
+                              f"in {wall:.1f} s (slowest worker {max(r['seconds'] for r in results):.1f} s, fastest "
+                              f"{min(r['seconds'] for r in results):.1f} s)"}
 
 
 def reference_parity(N, net_c, net_f, query):

@@ -74,7 +74,16 @@ def main():
     dt = time.perf_counter() - t0
     evals = a.n_rand * (a.samples + (a.samples + a.importance if a.importance else 0))
     flops = evals * 1186816 * 3          # forward + dX + dW
-    print(json.dumps({"metric": "train_iterations_per_sec", "value": a.iters / dt, "unit": "it/s",
+    # the step's big kernels by kind (HIP events on the step's stream, a short second run: not inside the reported it/s)
+    ctx = N.get_context()
+    ctx.profile_enable(True)
+    ctx.profile_read_train(reset=True)
+    for i in range(10):
+        one(i)
+    torch.cuda.synchronize()
+    ctx.profile_enable(False)
+    spans = {k: {"ms_per_iter": v[0] / 10, "launches_per_iter": v[1] / 10} for k, v in ctx.profile_read_train(reset=True).items()}
+    print(json.dumps({"metric": "train_iterations_per_sec", "value": a.iters / dt, "unit": "it/s", "kernels": spans,
                       "ms_per_iter": dt / a.iters * 1e3, "n_rand": a.n_rand, "N_samples": a.samples,
                       "N_importance": a.importance, "mlp_evals_per_iter": evals,
                       "approx_tflops": flops * a.iters / dt / 1e12, "final_loss": float(out["loss"]),

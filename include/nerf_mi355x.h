@@ -112,11 +112,17 @@ void nerf_ctx_destroy(nerf_ctx* ctx);
 #define NERF_PRECISION_F16X2 1
 int nerf_set_precision(nerf_ctx* ctx, int precision);
 int nerf_get_precision(nerf_ctx* ctx);
+/* The same for the RENDERING entry points only (nerf_render_rays / _frame / _shard and the stage calls): the training
+ * step keeps the arithmetic nerf_set_precision chose and any fp32 fallback it is in. This is what a caller that re-renders a
+ * range in fp32 after a precision warning uses (the Python mirror's batchify_rays): a validation render inside a training
+ * loop must not put the loop back on the fp16-pair kernels. nerf_get_precision returns the rendering arithmetic. */
+int nerf_set_render_precision(nerf_ctx* ctx, int precision);
 /* NERF_PRECISION_F16X2 chooses a layer's per-point output scale from an a-priori bound (largest row sum of |W| x
  * largest |input| + largest |bias|). A bound 2^12 or more above a point's real outputs starts to cost low-order
  * bits; each such (wavefront, layer) occurrence is counted, never silent. Synchronises the device; `reset` zeroes the
- * counter. 0 on every network trained or initialised like a NeRF; non-zero means: compare with NERF_PRECISION_F32 on
- * these weights (rows of large weights that cancel). */
+ * counters. The figure is the sum of two counters: the rendering calls' and the training step's (kept apart so that each
+ * side's guard sees only its own events). 0 on every network trained or initialised like a NeRF; non-zero means: compare
+ * with NERF_PRECISION_F32 on these weights (rows of large weights that cancel). */
 int nerf_precision_status(nerf_ctx* ctx, int64_t* loose_bound_events, int reset);
 /* Precision guard: how that counter reaches the caller without being asked for. The reference evaluates the network in
  * fp32 (nerf/nerf.py:57-111 under torch.float32, nerf.ipynb:76), so a loose bound must not pass silently:
@@ -129,9 +135,10 @@ int nerf_precision_status(nerf_ctx* ctx, int64_t* loose_bound_events, int reset)
  *                        have not been reported yet); nerf_precision_check synchronises `stream` first. Both mark what
  *                        they return as reported. The Python mirror peeks on entry of render_rays() and checks at the end
  *                        of batchify_rays(), which re-renders the chunks in fp32 when the check is positive.
- *   nerf_train_step      peeks on entry: if events of an earlier step have become visible the context's TRAINING switches
+ *   nerf_train_step      peeks on entry at ITS OWN counter (a frame rendered in between neither consumes a step's events nor
+ *                        adds to them): if events of an earlier step have become visible the context's TRAINING switches
  *                        to the fp32 kernels from this step on (until nerf_set_precision is called again) and the call
- *                        returns NERF_W_PRECISION_FALLBACK once. */
+ *                        returns NERF_W_PRECISION_FALLBACK once. nerf_precision_peek / _check report rendering's events only. */
 #define NERF_GUARD_OFF 0
 #define NERF_GUARD_REPORT 1
 #define NERF_GUARD_FALLBACK 2

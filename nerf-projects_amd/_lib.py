@@ -20,7 +20,7 @@ EXPORTS = (
     "nerf_get_gradients", "nerf_stratified_z", "nerf_resample", "nerf_render_frame", "nerf_set_precision",
     "nerf_get_precision", "nerf_precision_status", "nerf_get_adam_state", "nerf_set_adam_state",
     "nerf_shard_bounds", "nerf_render_shard", "nerf_precision_peek", "nerf_precision_check",
-    "nerf_precision_detail", "nerf_profile_read_train",
+    "nerf_precision_detail", "nerf_profile_read_train", "nerf_set_render_precision",
 )
 NERF_W_PRECISION, NERF_W_PRECISION_FALLBACK = 1, 2
 NERF_GUARD_OFF, NERF_GUARD_REPORT, NERF_GUARD_FALLBACK = 0, 1, 2
@@ -144,6 +144,8 @@ def load():
     lib.nerf_workspace_bytes.argtypes = [vp]
     lib.nerf_set_precision.restype = i32
     lib.nerf_set_precision.argtypes = [vp, i32]
+    lib.nerf_set_render_precision.restype = i32
+    lib.nerf_set_render_precision.argtypes = [vp, i32]
     lib.nerf_get_precision.restype = i32
     lib.nerf_get_precision.argtypes = [vp]
     lib.nerf_get_adam_state.restype = i32

@@ -100,16 +100,18 @@ int run_mlp(nerf_ctx* c, MlpLaunch& a, const PackedNet& net_in, int mode, hipStr
 namespace nerf {
 // Precision guard: the counter of loose scale bounds follows the work of this call to the pinned host mirror.
 hipError_t mirror_loose(nerf_ctx* c, hipStream_t s) {
-    if (c->precision != NERF_PRECISION_F16X2 || !c->h_loose) return hipSuccess;
-    return hipMemcpyAsync(c->h_loose, c->d_loose, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    if ((c->precision != NERF_PRECISION_F16X2 && c->train_precision != NERF_PRECISION_F16X2) || !c->h_loose) return hipSuccess;
+    return hipMemcpyAsync(c->h_loose, c->d_loose, kLooseWords * sizeof(unsigned), hipMemcpyDeviceToHost, s);
 }
 // events in the mirror that no call has reported yet; marks them reported
-unsigned take_new_loose(nerf_ctx* c) {
-    const unsigned v = c->h_loose ? *(volatile unsigned*)c->h_loose : 0u;
-    const unsigned n = v - c->loose_seen;      // (the counter only grows between resets; a reset zeroes both)
-    c->loose_seen = v;
+static unsigned take_new(const nerf_ctx* c, int word, unsigned& seen) {
+    const unsigned v = c->h_loose ? ((volatile unsigned*)c->h_loose)[word] : 0u;
+    const unsigned n = v - seen;      // (a counter only grows between resets; a reset zeroes both)
+    seen = v;
     return n;
 }
+unsigned take_new_loose(nerf_ctx* c) { return take_new(c, 0, c->loose_seen); }
+unsigned take_new_loose_train(nerf_ctx* c) { return take_new(c, kLooseTrain, c->train_loose_seen); }
 
 EqualiseRefs equalise_refs(const nerf_arch& a, const std::vector<LinearDesc>& linears) {
     EqualiseRefs r{};
@@ -308,8 +310,8 @@ int nerf_ctx_create(int device, nerf_ctx** out) {
         DeviceGuard g(device);
         hipError_t e2 = hipMalloc((void**)&c->d_loose, kLooseWords * sizeof(unsigned));
         if (e2 == hipSuccess) e2 = hipMemset(c->d_loose, 0, kLooseWords * sizeof(unsigned));
-        if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&c->h_loose, sizeof(unsigned), hipHostMallocDefault);
-        if (e2 == hipSuccess) *c->h_loose = 0u;
+        if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&c->h_loose, kLooseWords * sizeof(unsigned), hipHostMallocDefault);
+        if (e2 == hipSuccess) memset(c->h_loose, 0, kLooseWords * sizeof(unsigned));
         if (e2 != hipSuccess) {
             set_error("nerf_ctx_create: device allocation failed: %s", hipGetErrorString(e2));
             delete c;
@@ -348,7 +350,17 @@ int nerf_set_precision(nerf_ctx* c, int precision) {
         return NERF_E_INVALID;
     }
     c->precision = precision;
+    c->train_precision = precision;
     c->train_force_f32 = false;      // an explicit choice ends a fallback of the training path (nerf_train_step)
+    return NERF_OK;
+}
+
+int nerf_set_render_precision(nerf_ctx* c, int precision) {
+    if (!c || (precision != NERF_PRECISION_F32 && precision != NERF_PRECISION_F16X2)) {
+        set_error("nerf_set_render_precision: invalid argument");
+        return NERF_E_INVALID;
+    }
+    c->precision = precision;        // (the training step's arithmetic and a fallback it is in stay as they are)
     return NERF_OK;
 }
 
@@ -415,8 +427,9 @@ int nerf_load_weights(nerf_ctx* c, int slot, const nerf_arch* arch, const float*
         // index table of the fused backward-data kernel's stream (training; view-dependent networks only)
         net.bwd_table.clear();
         // (narrower networks, one-layer trunks without a view branch and heads of more than kBwdMaxOutRows channels train on
-        // the layer-by-layer chain)
-        if (arch->W == kWidth && (arch->use_viewdirs || (arch->output_ch <= kBwdMaxOutRows && arch->D >= 2))) {
+        // the layer-by-layer chain; so does a head whose per-register rows did not fit the bias block, pack_weights.cpp)
+        if (arch->W == kWidth && (arch->use_viewdirs || (arch->output_ch <= kBwdMaxOutRows && arch->D >= 2 &&
+                                                         nbt >= 8 * arch->D + 1 + 8 * arch->output_ch))) {
             float* tsb = nullptr;
             int nbc = 0;
             rc = pack_backward_stream(*arch, fake_ptrs.data(), mask, &tsb, &nbc);
@@ -931,15 +944,15 @@ int nerf_precision_status(nerf_ctx* c, int64_t* loose_bound_events, int reset) {
         return NERF_E_INVALID;
     }
     DeviceGuard g(c->device);
-    unsigned v = 0;
+    unsigned v[kLooseWords] = {};
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(&v, c->d_loose, sizeof(v), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(v, c->d_loose, sizeof(v), hipMemcpyDeviceToHost));
     if (reset) {
         HIP_TRY(hipMemset(c->d_loose, 0, kLooseWords * sizeof(unsigned)));
-        if (c->h_loose) *c->h_loose = 0u;
-        c->loose_seen = 0u;
+        if (c->h_loose) memset(c->h_loose, 0, kLooseWords * sizeof(unsigned));
+        c->loose_seen = c->train_loose_seen = 0u;
     }
-    *loose_bound_events = (int64_t)v;
+    *loose_bound_events = (int64_t)v[0] + (int64_t)v[kLooseTrain];      // rendering's and the training step's
     return NERF_OK;
 }
 
@@ -954,10 +967,10 @@ int nerf_precision_detail(nerf_ctx* c, int64_t* counts, int reset) {
     HIP_TRY(hipMemcpy(v, c->d_loose, sizeof(v), hipMemcpyDeviceToHost));
     if (reset) {
         HIP_TRY(hipMemset(c->d_loose, 0, sizeof(v)));
-        if (c->h_loose) *c->h_loose = 0u;
-        c->loose_seen = 0u;
+        if (c->h_loose) memset(c->h_loose, 0, kLooseWords * sizeof(unsigned));
+        c->loose_seen = c->train_loose_seen = 0u;
     }
-    for (int i = 0; i < kLooseWords; ++i) counts[i] = (int64_t)v[i];
+    for (int i = 0; i < kLooseTrain; ++i) counts[i] = (int64_t)v[i] + (int64_t)v[kLooseTrain + i];
     return NERF_OK;
 }
 

@@ -19,14 +19,19 @@
 
 struct nerf_ctx {
     int device = 0;
-    int precision = NERF_PRECISION_F16X2;   // arithmetic of the fused MLP kernel (nerf_set_precision)
+    int precision = NERF_PRECISION_F16X2;   // arithmetic of the fused MLP kernel in the RENDERING calls (nerf_set_precision,
+                                            // nerf_set_render_precision)
+    int train_precision = NERF_PRECISION_F16X2;   // ... in nerf_train_step (nerf_set_precision only)
     nerf::PackedNet nets[NERF_NUM_SLOTS];
     unsigned* d_loose = nullptr;   // see nerf_precision_status
-    // The precision guard (nerf_mi355x.h, "Precision guard"): a pinned host mirror of d_loose, refreshed by a 4-byte copy
+    // The precision guard (nerf_mi355x.h, "Precision guard"): a pinned host mirror of d_loose, refreshed by a 64-byte copy
     // enqueued behind every render / training call, so that a later call can see - without synchronising - whether the
-    // fp16-pair kernel's scale bound was loose in work that has completed; `loose_seen` is the count already reported.
+    // fp16-pair kernel's scale bound was loose in work that has completed. Rendering counts in word 0, the training step in
+    // word kLooseTrain, and each has its own cursor of what has been reported (`loose_seen`, `train_loose_seen`): a frame
+    // rendered after a loose training step does not take that step's events, nor the other way round.
     unsigned* h_loose = nullptr;
     unsigned loose_seen = 0;
+    unsigned train_loose_seen = 0;
     bool train_force_f32 = false;  // set by nerf_train_step when it sees new events: training continues on the fp32 kernels
     char* ws = nullptr;          // workspace arena
     size_t ws_bytes = 0;
@@ -61,7 +66,8 @@ struct nerf_ctx {
 namespace nerf {
 
 hipError_t mirror_loose(nerf_ctx* c, hipStream_t s);     // api.cpp: the precision guard's counter mirror
-unsigned take_new_loose(nerf_ctx* c);
+unsigned take_new_loose(nerf_ctx* c);                    // rendering's events not yet reported; marks them reported
+unsigned take_new_loose_train(nerf_ctx* c);              // the training step's
 
 // HIP events around a stretch of a training step's launches (only while nerf_profile_enable is on)
 struct TrainTimer {

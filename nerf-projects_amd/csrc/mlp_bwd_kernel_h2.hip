@@ -113,7 +113,7 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
     //   when the layer's chunks begin, read when they end)
     __shared__ __attribute__((aligned(16))) char pre_lds[kWavesPerGroup][3][kPreSlotBytes];
     __shared__ unsigned max_record[kBwdMaxSlots];                      // enter_max: this workgroup's maxima, flushed at the end
-    __shared__ unsigned loose_hist[kLooseWords];                       // this workgroup's loose-bound events, flushed at the end
+    __shared__ unsigned loose_hist[kLooseRecord];                       // this workgroup's loose-bound events, flushed at the end
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
@@ -129,7 +129,7 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
     // rgb_linear's rows: bias-block tiles 8D+22 .. 8D+33 (pack_weights.cpp row_tiles)
     for (int i = threadIdx.x; i < kRgbRowFloats; i += 256) rgb_lds[i] = b.bias[(8 * D + 22) * kBiasTileFloats + i];
     if (threadIdx.x < kBwdMaxSlots) max_record[threadIdx.x] = 0u;
-    if (threadIdx.x < kLooseWords) loose_hist[threadIdx.x] = 0u;
+    if (threadIdx.x < kLooseRecord) loose_hist[threadIdx.x] = 0u;
     if ((int)threadIdx.x <= D) {
         const int l = threadIdx.x;
         layer_tab[4 * l] = b.descale[l];
@@ -243,10 +243,16 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
                 pd.mask = u32x4{~0u, ~0u, ~0u, ~0u};
                 pd.keep_base = wave_uniform(b.out.feat);
                 pd.keep_off = 4u * ((unsigned)pt * (unsigned)b.out.feat_ld + 4u * (unsigned)h);
+#ifdef NERF_EXP_STORE_BLOCKED
+                pd.keep_off = 4u * (((unsigned)pt >> 5) * 32u * (unsigned)b.out.feat_ld + ((unsigned)pt & 31u) * 8u + (unsigned)h * 4u);
+#endif
             } else {
                 pd.mask = u32x4{__float_as_uint(mk[0]), __float_as_uint(mk[1]), __float_as_uint(mk[2]), __float_as_uint(mk[3])};
                 pd.keep_base = wave_uniform(b.out.h[D - bl]);
                 pd.keep_off = 4u * ((unsigned)pt * (unsigned)b.out.h_ld[D - bl] + 4u * (unsigned)h);
+#ifdef NERF_EXP_STORE_BLOCKED
+                pd.keep_off = 4u * (((unsigned)pt >> 5) * 32u * (unsigned)b.out.h_ld[D - bl] + ((unsigned)pt & 31u) * 8u + (unsigned)h * 4u);
+#endif
             }
         };
         auto close_pending = [&](int slot) {
@@ -330,7 +336,7 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
     }   // tile loop
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    if (b.loose && threadIdx.x < kLooseWords && loose_hist[threadIdx.x]) atomicAdd(b.loose + threadIdx.x, loose_hist[threadIdx.x]);
+    if (b.loose && threadIdx.x < kLooseRecord && loose_hist[threadIdx.x]) atomicAdd(b.loose + threadIdx.x, loose_hist[threadIdx.x]);
     flush_maxes(b.maxes, max_record, kBwdMaxSlots);
 }
 

@@ -92,12 +92,12 @@ __device__ __forceinline__ void keep_pairs(const Pending& pd, const f32x2& even,
     return;
 #endif
 #ifdef NERF_EXP_STORE_BLOCKED
-    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(pd.keep_off + (8u * T + 2u * Q) * 512u), "v"(v), "s"(pd.keep_base) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2" NERF_STORE_POLICY "\n\ts_nop 1" : : "v"(pd.keep_off + (8u * T + 2u * Q) * 512u), "v"(v), "s"(pd.keep_base) : "memory");
     return;
 #endif
     // (s_nop 1: a store of more than 8 bytes reads its data registers late - two wait states before a vector instruction
     // may overwrite them on gfx950; hipcc's hazard recogniser does not look inside inline asm)
-    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1"
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" NERF_STORE_POLICY "\n\ts_nop 1"
                  :
                  : "v"(pd.keep_off), "v"(v), "s"(pd.keep_base), "n"((32 * T + 8 * Q) * 4)
                  : "memory");

@@ -112,10 +112,13 @@ struct PackedNet {
     int out_ch = 4;              // channels NeRF.forward returns
 };
 
-// nerf_ctx::d_loose: word 0 is the counter the precision guard watches (nerf_precision_status); words 1..7 a histogram of the
-// backward-data kernel's (wavefront, layer) events by how far the a-priori bound overshot: 2^12-13, 2^14-15, ..., >= 2^24
-// (nerf_precision_detail)
-constexpr int kLooseWords = 8;
+// nerf_ctx::d_loose: two records of 8 words, the rendering calls' at 0 and the training step's at kLooseTrain (the kernels
+// get the record's address). Word 0 of a record is the counter the precision guard watches (nerf_precision_status); words
+// 1..7 a histogram of the backward-data kernel's (wavefront, layer) events by how far the a-priori bound overshot: 2^12-13,
+// 2^14-15, ..., >= 2^24 (nerf_precision_detail; only the training record's fill)
+constexpr int kLooseRecord = 8;
+constexpr int kLooseWords = 2 * kLooseRecord;
+constexpr int kLooseTrain = kLooseRecord;
 constexpr int kLooseBwdGuard = 1000;    // overshoot (in binades) from which a backward event would also count for the guard:
                                         // never (nerf_mi355x.h, nerf_precision_detail, says why)
 

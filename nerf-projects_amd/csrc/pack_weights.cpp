@@ -307,7 +307,10 @@ int pack_weights(const nerf_arch& a, const float* const* tensors, int n_tensors,
         // output_linear's rows once more per accumulator register (tiles 8D+1+8c .. +8 for row c): the backward-data pass of
         // the training step turns d raw into d h_{D-1} with them (nerf_mlp_bwd_kernel); only for the channel counts the
         // reference builds (4, or 5 with N_importance > 0, nerf.ipynb:885) - a 32-channel head would not fit the bias block
-        if (a.output_ch <= kBwdMaxOutRows)
+        // and only when they fit it: a deep trunk with a wide head (D = 12, 8 channels: 161 tiles) loads without them for
+        // inference and trains on the layer-by-layer chain (nerf_load_weights leaves the backward stream out)
+        if (a.output_ch <= kBwdMaxOutRows &&
+            (bias.size() + (size_t)8 * a.output_ch * kBiasTileFloats) * sizeof(float) <= (size_t)kBiasLdsBytes)
             for (int c = 0; c < a.output_ch; ++c) row_tiles(bias, outl, c, 8);
         *out_ch = a.output_ch;
     }

@@ -69,7 +69,7 @@ std::vector<int> bwd_chunk_layers(const nerf_arch& a) {
 int refresh_bwd(PackedNet& net, bool eq, bool pair, hipStream_t s) {
     TrainState& t = net.train;
     if (!t.d_stream_bwd) return NERF_OK;
-    const bool have_pair = t.d_stream_bwd_h2 != nullptr;
+    const bool have_pair = t.d_stream_bwd_h2 && t.d_descale_bwd && t.d_gain_bwd && t.d_chunk_layer_bwd && t.d_chunk_max_bwd;
     if (!t.bwd_dirty && t.bwd_is_eq == eq && (!pair || have_pair)) return NERF_OK;
     HIP_TRY(launch_gather(eq ? net.d_params_eq : net.d_params, t.d_bwd_table, (int64_t)net.bwd_table.size(), t.d_stream_bwd, s));
     t.bwd_is_eq = eq;
@@ -81,13 +81,28 @@ int refresh_bwd(PackedNet& net, bool eq, bool pair, hipStream_t s) {
                 set_error("internal: %zu scale groups for %d backward chunks", ids.size(), nb);
                 return NERF_E_INVALID;
             }
-            HIP_TRY(hipMalloc((void**)&t.d_stream_bwd_h2, (size_t)(nb + kStreamTailChunks) * kChunkBytes));
-            HIP_TRY(hipMalloc((void**)&t.d_descale_bwd, (kMaxDepth + 3) * sizeof(float)));
-            HIP_TRY(hipMalloc((void**)&t.d_gain_bwd, 2 * (kMaxDepth + 2) * sizeof(float)));
-            HIP_TRY(hipMalloc((void**)&t.d_chunk_layer_bwd, (size_t)nb * sizeof(int)));
-            HIP_TRY(hipMalloc((void**)&t.d_chunk_max_bwd, (size_t)nb * sizeof(float)));
-            HIP_TRY(hipMemcpyAsync(t.d_chunk_layer_bwd, ids.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, s));
-            HIP_TRY(hipStreamSynchronize(s));      // (`ids` is a host temporary; once per slot)
+            // all five or none: a step after a failed allocation must find the slot without a pair stream, not half of one
+            void* buf[5] = {};
+            const size_t bytes[5] = {(size_t)(nb + kStreamTailChunks) * kChunkBytes, (kMaxDepth + 3) * sizeof(float),
+                                     2 * (kMaxDepth + 2) * sizeof(float), (size_t)nb * sizeof(int), (size_t)nb * sizeof(float)};
+            hipError_t e = hipSuccess;
+            for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipMalloc(&buf[i], bytes[i]);
+            if (e == hipSuccess) e = hipMemcpyAsync(buf[3], ids.data(), bytes[3], hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);      // (`ids` is a host temporary; once per slot)
+            if (e != hipSuccess) {
+                for (void* b : buf)
+                    if (b) (void)hipFree(b);
+                set_error("refresh_bwd: allocating the fp16-pair backward stream failed: %s", hipGetErrorString(e));
+                return e == hipErrorOutOfMemory ? NERF_E_NOMEM : NERF_E_HIP;
+            }
+            for (void** old : {(void**)&t.d_stream_bwd_h2, (void**)&t.d_descale_bwd, (void**)&t.d_gain_bwd,
+                               (void**)&t.d_chunk_layer_bwd, (void**)&t.d_chunk_max_bwd})
+                if (*old) (void)hipFree(*old);
+            t.d_stream_bwd_h2 = (uint32_t*)buf[0];
+            t.d_descale_bwd = (float*)buf[1];
+            t.d_gain_bwd = (float*)buf[2];
+            t.d_chunk_layer_bwd = (int*)buf[3];
+            t.d_chunk_max_bwd = (float*)buf[4];
         }
         HIP_TRY(launch_convert_stream_h2(t.d_stream_bwd, t.d_chunk_layer_bwd, nb, t.d_chunk_max_bwd, t.d_stream_bwd_h2,
                                          t.d_descale_bwd, s));
@@ -756,11 +771,11 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     // Precision guard (nerf_mi355x.h): events counted by work that has completed since the last look - earlier steps of
     // this loop, typically - move the training path to the fp32 kernels, from this step on and until nerf_set_precision
     bool fell_back = false;
-    if (c->precision == NERF_PRECISION_F16X2 && !c->train_force_f32 && take_new_loose(c) > 0) {
+    if (c->train_precision == NERF_PRECISION_F16X2 && !c->train_force_f32 && take_new_loose_train(c) > 0) {
         c->train_force_f32 = true;
         fell_back = true;
     }
-    const int precision = c->train_force_f32 ? NERF_PRECISION_F32 : c->precision;
+    const int precision = c->train_force_f32 ? NERF_PRECISION_F32 : c->train_precision;
     for (PackedNet* n : {&nc, &nf}) {
         const bool fresh = !n->train.ready;
         if ((rc = ensure_train_state(c, *n))) return rc;
@@ -798,7 +813,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     pc.fused_backward = !gemm_backward_requested() && nc.train.d_stream_bwd != nullptr && (nc.out_ch == 4 || !nc.arch.use_viewdirs);
     pc.precision = precision;
     pc.ctx = c;
-    pc.loose = c->d_loose;
+    pc.loose = c->d_loose + kLooseTrain;
     set_units(pc);
     carve_pass(ar, pc);
     Pass pf;
@@ -810,7 +825,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
         pf.fused_backward = !gemm_backward_requested() && nf.train.d_stream_bwd != nullptr && (nf.out_ch == 4 || !nf.arch.use_viewdirs);
         pf.precision = precision;
         pf.ctx = c;
-        pf.loose = c->d_loose;
+        pf.loose = c->d_loose + kLooseTrain;
         set_units(pf);
         carve_pass(ar, pf);
     }

@@ -44,6 +44,7 @@ class Context:
         check(lib.nerf_ctx_create(device_index, C.byref(handle)))
         self.handle = handle
         self._slots = [None] * _lib.NERF_NUM_SLOTS
+        self._chunk_loop = 0       # > 0 while batchify_rays owns the precision guard's events (see _peek_precision)
         default = os.environ.get("NERF_PRECISION")
         if default:
             self.set_precision(default)
@@ -55,6 +56,13 @@ class Context:
         if name not in self.PRECISIONS:
             raise ValueError(f"precision {name!r}: expected one of {sorted(self.PRECISIONS)}")
         check(self.lib.nerf_set_precision(self.handle, self.PRECISIONS[name]))
+
+    def set_render_precision(self, name):
+        """The same for the rendering calls only: the training step keeps its arithmetic and any fp32 fallback it is in
+        (nerf_set_render_precision); ``get_precision`` reports this one."""
+        if name not in self.PRECISIONS:
+            raise ValueError(f"precision {name!r}: expected one of {sorted(self.PRECISIONS)}")
+        check(self.lib.nerf_set_render_precision(self.handle, self.PRECISIONS[name]))
 
     def precision_status(self, reset=True):
         """Number of (wavefront, layer) events since the last reset in which the fp16-pair kernel's a-priori output
@@ -124,8 +132,10 @@ _LOOSE = ("the fp16-pair MLP kernel's output-scale bound was loose in {n} (wavef
 
 
 def _peek_precision(ctx, where):
-    """Entry of an asynchronous call: report (never hide) what completed work has counted since the last look."""
-    if ctx.get_precision() != "f16x2":
+    """Entry of an asynchronous call: report (never hide) what completed work has counted since the last look. Inside
+    ``batchify_rays``' chunk loop the events belong to that call - it checks behind its last chunk and renders the rays
+    again in fp32 - so a chunk's entry must not mark an earlier chunk's events as reported."""
+    if ctx._chunk_loop or ctx.get_precision() != "f16x2":
         return 0
     n = ctx.precision_peek()
     if n:
@@ -692,22 +702,30 @@ def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
                 all_ret.setdefault(k, []).append(ret[k])
         return {k: torch.cat(all_ret[k], dim=0) for k in all_ret}
 
-    out = run()
-    # Precision guard: the reference evaluates the network in fp32 (nerf.ipynb:76). If the fp16-pair kernel counted a loose
-    # scale bound on these rays, they are rendered again by the fp32 kernel - one 4-byte read behind the last chunk.
     net = kwargs.get('network_fn')
     ctx = getattr(net, 'ctx', None)
-    if out and ctx is not None and ctx.get_precision() == "f16x2":
-        n = ctx.precision_check()
+    if ctx is None or ctx.get_precision() != "f16x2":
+        return run()
+    # Precision guard: the reference evaluates the network in fp32 (nerf.ipynb:76). If the fp16-pair kernel counted a loose
+    # scale bound on these rays, they are rendered again by the fp32 kernel - one look at the counter behind the last chunk.
+    # What earlier calls counted is reported here, once; from then on every event up to the check belongs to these rays,
+    # whichever chunk it came from and however far the GPU has got when the next chunk is entered.
+    _peek_precision(ctx, "batchify_rays")
+    ctx._chunk_loop += 1
+    try:
+        out = run()
+        n = ctx.precision_check() if out else 0
         if n:
             import warnings
             warnings.warn("batchify_rays: " + _LOOSE.format(n=n) + "; these rays were rendered again with the fp32 kernel",
                           RuntimeWarning, stacklevel=2)
-            ctx.set_precision("f32")
+            ctx.set_render_precision("f32")      # (rendering only: a training loop around this call keeps its arithmetic)
             try:
                 out = run()
             finally:
-                ctx.set_precision("f16x2")
+                ctx.set_render_precision("f16x2")
+    finally:
+        ctx._chunk_loop -= 1
     return out
 
 

@@ -190,6 +190,20 @@ def synthetic_pair(seed=0, **arch):
     return coarse, perturbed_copy(coarse, seed + 1)
 
 
+def default_init_state_dict(seed, **arch):
+    """What a freshly constructed reference ``NeRF`` holds, up to the random stream: ``nn.Linear``'s default
+    initialisation draws weight AND bias from U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (kaiming_uniform_ with a = sqrt(5);
+    the modules of nerf/nerf.py:32-55 are never re-initialised). The state a training run starts from."""
+    rs = np.random.RandomState(seed)
+    out = OrderedDict()
+    bound = 0.0
+    for k, shape in state_dict_shapes(**arch).items():
+        if k.endswith(".weight"):
+            bound = 1.0 / np.sqrt(shape[1])
+        out[k] = rs.uniform(-bound, bound, size=shape).astype(np.float32)
+    return out
+
+
 def state_dict_digest(sd):
     """sha256 over names, shapes and bytes; fixtures store it to detect a host on
     which the seeded generator does not reproduce the build container's weights."""

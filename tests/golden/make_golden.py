@@ -512,10 +512,16 @@ def gold_train_adam_state():
             for it in range(2):
                 ret = NS["render_rays"](rays, net_c, query_fn(e_fn, ed_fn), network_fine=net_f, **kw)
                 opt.zero_grad()
-                loss = ref_helpers.img2mse(ret["rgb_map"], target) + ref_helpers.img2mse(ret["rgb0"], target)
+                img_loss, img_loss0 = ref_helpers.img2mse(ret["rgb_map"], target), ref_helpers.img2mse(ret["rgb0"], target)
+                loss = img_loss + img_loss0
                 loss.backward()
                 opt.step()
+                # (round 4) both runs' losses and final weights: the yardstick of test_two_adam_steps_match_reference
+                out[f"img_loss_{it}{tag}"], out[f"img_loss0_{it}{tag}"] = img_loss.item(), img_loss0.item()
             sd = opt.state_dict()
+            for t2, net in (("c", net_c), ("f", net_f)):
+                for k, p in net.named_parameters():
+                    out[f"wsub_{t2}.{k}{tag}"] = n(p).reshape(-1)[::61].copy()
         finally:
             torch.set_default_dtype(old)
         if tag == "":
@@ -525,6 +531,79 @@ def gold_train_adam_state():
             out[f"exp_avg.{i}{tag}"] = n(st["exp_avg"]).reshape(-1)[::61].copy()
             out[f"exp_avg_sq.{i}{tag}"] = n(st["exp_avg_sq"]).reshape(-1)[::61].copy()
     save("train_step_adam", **out)
+
+
+def _loop_batches(n_iters=20, n_rand=256):
+    """The batches of gold_train_loop: the reference's use_batching mode (nerf.ipynb:1209-1230) over the 4096 bench-frame
+    rays - one shuffle (RandomState(107)), consecutive windows of N_rand, wrapping after an epoch - and a target image
+    that the networks can move towards: the reference's own render of those rays mixed with a colour ramp over the frame."""
+    g = np.load(os.path.join(HERE, "bench_frame.npz"))
+    perm = np.random.RandomState(107).permutation(len(g["rays"]))
+    u, v = (g["pix"] % 800) / 799.0, (g["pix"] // 800) / 799.0
+    ramp = np.stack([u, v, 1.0 - u], -1)
+    target = np.clip(0.6 * g["rgb_map"].astype(np.float64) + 0.4 * ramp, 0.0, 1.0).astype(np.float32)
+    idx = [perm[(i * n_rand) % len(perm):(i * n_rand) % len(perm) + n_rand] for i in range(n_iters)]
+    return g["rays"], target, perm, idx
+
+
+def gold_train_loop():
+    """TWENTY iterations of the reference's training loop body (nerf.ipynb:1258-1282: render with the training kwargs and
+    its pytest RNG, both MSEs, backward, torch.optim.Adam, the exponential lr decay of :1278-1282) at N_rand = 256, 64+128,
+    run by the reference in float32 AND in float64 on the same batches: both loss curves, both PSNR curves and every 61st
+    element of the final weights. The distance between the two runs is the yardstick for a third implementation.
+    Two starts: ``init`` - networks as nn.Linear initialises them (synthetic.default_init_state_dict, seeds 11 / 12: what
+    training starts from) for 20 iterations; ``pair`` - the synthetic scene of the other fixtures for 8: Adam's first
+    step (every weight by lr) throws that hand-calibrated field far off, which a third implementation must follow too."""
+    rays_np, target_np, perm, idx = _loop_batches()
+    lrate, lrate_decay, decay_rate = 5e-4, 500, 0.1          # nerf/yaml/lego_blender200k_fullres
+    out = {"perm": perm, "target": target_np, "n_rand": len(idx[0]), "lrate": lrate, "lrate_decay": lrate_decay}
+    starts = {"init": ((synthetic.default_init_state_dict(11), synthetic.default_init_state_dict(12)), 20),
+              "pair": (synthetic.synthetic_pair(0), 8)}
+    for start, ((sd_c, sd_f), n_iters) in starts.items():
+        out[f"{start}.n_iters"] = n_iters
+        out[f"{start}.digest_c"], out[f"{start}.digest_f"] = synthetic.state_dict_digest(sd_c), synthetic.state_dict_digest(sd_f)
+        for tag, dtype in (("", torch.float32), (".f64", torch.float64)):
+            old = torch.get_default_dtype()
+            torch.set_default_dtype(dtype)
+            try:
+                net_c, net_f = ref_model(None, dtype, sd=sd_c), ref_model(None, dtype, sd=sd_f)
+                net_c.train(); net_f.train()
+                e_fn, _ = ref_embedder.get_embedder(10, 0)
+                ed_fn, _ = ref_embedder.get_embedder(4, 0)
+                params = list(net_c.parameters()) + list(net_f.parameters())
+                opt = torch.optim.Adam(params=params, lr=lrate, betas=(0.9, 0.999))
+                kw = dict(N_samples=64, N_importance=128, retraw=True, white_bkgd=True, perturb=1.0, raw_noise_std=1.0,
+                          pytest=True)
+                losses, losses0, psnrs = [], [], []
+                global_step = 0
+                for it, sel in enumerate(idx[:n_iters]):
+                    rays = torch.from_numpy(rays_np[sel]).to(dtype)
+                    target = torch.from_numpy(target_np[sel]).to(dtype)
+                    ret = NS["render_rays"](rays, net_c, query_fn(e_fn, ed_fn), network_fine=net_f, **kw)
+                    opt.zero_grad()
+                    img_loss = ref_helpers.img2mse(ret["rgb_map"], target)
+                    psnr = ref_helpers.mse2psnr(img_loss)
+                    img_loss0 = ref_helpers.img2mse(ret["rgb0"], target)
+                    loss = img_loss + img_loss0
+                    loss.backward()
+                    opt.step()
+                    decay_steps = lrate_decay * 1000
+                    new_lrate = lrate * (decay_rate ** (global_step / decay_steps))
+                    for param_group in opt.param_groups:
+                        param_group["lr"] = new_lrate
+                    global_step += 1
+                    losses.append(img_loss.item()); losses0.append(img_loss0.item()); psnrs.append(psnr.item())
+                    print(f"    train_loop {start}{tag} {it}: {losses[-1]:.6f} {losses0[-1]:.6f}", flush=True)
+            finally:
+                torch.set_default_dtype(old)
+            out[f"{start}.img_loss{tag}"] = np.array(losses, np.float64)
+            out[f"{start}.img_loss0{tag}"] = np.array(losses0, np.float64)
+            out[f"{start}.psnr{tag}"] = np.array(psnrs, np.float64)
+            if start == "init":
+                for t2, net in (("c", net_c), ("f", net_f)):
+                    for k, p in net.named_parameters():
+                        out[f"{start}.wsub_{t2}.{k}{tag}"] = n(p).reshape(-1)[::61].copy()
+    save("train_loop", **out)
 
 
 def gold_train_variants():
@@ -841,6 +920,7 @@ if __name__ == "__main__":
     gold_train()
     gold_train_variants()
     gold_train_adam_state()
+    gold_train_loop()
     gold_widths()
     gold_train_noviewdirs()
     gold_train_depths()

@@ -131,3 +131,17 @@ def test_package_import_sets_it_for_library_users(monkeypatch):
     assert N.ensure_ipc_env() == "0" and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
     assert N.ensure_ipc_env() == "1"
+
+
+def test_whole_host_cpu_baseline_runs_worker_processes(bench):
+    """cpu_baseline's second leg: P worker processes x T threads on disjoint ray slices, started
+    together, GPU hidden from them; the record names P, T and the aggregate rate."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "render_rays_lego.npz"))
+    out = bench.cpu_baseline_all_cores(g["rays"][:256], 8, 8, True, threads=1, ncpu=2, single_pool_rate=2e4, target_s=1.0)
+    assert out["processes"] == 2 and out["threads_per_process"] == 1 and out["cores_all"] == 2, out
+    assert out["value_all_cores"] and out["value_all_cores"] > 0, out
+    # one process already covering the host: nothing to add
+    one = bench.cpu_baseline_all_cores(g["rays"][:64], 8, 8, True, threads=8, ncpu=8, single_pool_rate=5.0, target_s=1.0)
+    assert one["processes"] == 1 and one["value_all_cores"] == 5.0
