@@ -287,6 +287,14 @@ typedef struct nerf_camera {
 int nerf_generate_rays(nerf_ctx* ctx, const nerf_camera* cam, int64_t first_pixel, int64_t n_pixels,
                        float* rays /*[dev] [n_pixels, 8|11]*/, void* stream);
 
+/* render(rays=(rays_o, rays_d), ...) - the form the training loop calls (nerf.ipynb:1258) - packs a caller-supplied batch:
+ * viewdirs = rays_d / |rays_d| taken before the NDC warp (nerf.ipynb:600-614), optional ndc_rays(H, W, K[0][0], 1., ...)
+ * (:616-619), near / far columns (:622-629) -> the [n, 8|11] ray record. Of `cam` only H, W, ndc, ndc_focal, near, far and
+ * use_viewdirs are read. rays_o / rays_d are [n, >= 3] with row strides of o_stride / d_stride floats (so that the two
+ * halves of a stacked record can be passed in place). One kernel instead of the six tensor operations of the reference. */
+int nerf_pack_rays(nerf_ctx* ctx, const nerf_camera* cam, const float* rays_o /*[dev]*/, int o_stride,
+                   const float* rays_d /*[dev]*/, int d_stride, int64_t n, float* rays /*[dev] [n, 8|11]*/, void* stream);
+
 /* render() for one camera (nerf.ipynb:558-640) in a single call: ray generation for the flat pixel range
  * [first_pixel, first_pixel + n_pixels), the batchify_rays chunk loop and render_rays per chunk, all enqueued
  * on `stream` with no host synchronisation. Deterministic rendering only (perturb = 0, raw_noise_std = 0:
@@ -363,6 +371,9 @@ typedef struct nerf_train_args {
     float* rgb_map;             /* [dev] [N,3] optional                                         */
     float* rgb0;                /* [dev] [N,3] optional                                         */
     void* stream;
+    float* stats;               /* [dev] [5] optional: img_loss, img_loss0, loss = their sum, psnr = mse2psnr(img_loss), psnr0
+                                   (nerf.ipynb:1262-1272, nerf_helpers.py:14) - what the loop body prints, without a tensor
+                                   operation per number (entries 1 and 4 are 0 when N_importance = 0)            */
 } nerf_train_args;
 
 int nerf_train_step(nerf_ctx* ctx, const nerf_train_args* args);

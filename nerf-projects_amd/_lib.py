@@ -21,6 +21,7 @@ EXPORTS = (
     "nerf_get_precision", "nerf_precision_status", "nerf_get_adam_state", "nerf_set_adam_state",
     "nerf_shard_bounds", "nerf_render_shard", "nerf_precision_peek", "nerf_precision_check",
     "nerf_precision_detail", "nerf_profile_read_train", "nerf_set_render_precision",
+    "nerf_pack_rays",
 )
 NERF_W_PRECISION, NERF_W_PRECISION_FALLBACK = 1, 2
 NERF_GUARD_OFF, NERF_GUARD_REPORT, NERF_GUARD_FALLBACK = 0, 1, 2
@@ -52,7 +53,8 @@ class TrainArgs(C.Structure):
                 ("slot_fine", C.c_int32), ("lindisp", C.c_int32), ("white_bkgd", C.c_int32), ("perturb", C.c_int32),
                 ("t_rand", _FP), ("u_rand", _FP), ("noise0", _FP), ("noise", _FP), ("lr", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int32),
-                ("apply_update", C.c_int32), ("loss", _FP), ("rgb_map", _FP), ("rgb0", _FP), ("stream", C.c_void_p)]
+                ("apply_update", C.c_int32), ("loss", _FP), ("rgb_map", _FP), ("rgb0", _FP), ("stream", C.c_void_p),
+                ("stats", _FP)]
 
 
 class Camera(C.Structure):
@@ -144,6 +146,8 @@ def load():
     lib.nerf_workspace_bytes.argtypes = [vp]
     lib.nerf_set_precision.restype = i32
     lib.nerf_set_precision.argtypes = [vp, i32]
+    lib.nerf_pack_rays.restype = i32
+    lib.nerf_pack_rays.argtypes = [vp, C.POINTER(Camera), vp, i32, vp, i32, i64, vp, vp]
     lib.nerf_set_render_precision.restype = i32
     lib.nerf_set_render_precision.argtypes = [vp, i32]
     lib.nerf_get_precision.restype = i32

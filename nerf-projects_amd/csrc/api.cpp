@@ -744,6 +744,26 @@ int nerf_generate_rays(nerf_ctx* c, const nerf_camera* cam, int64_t first_pixel,
     return NERF_OK;
 }
 
+int nerf_pack_rays(nerf_ctx* c, const nerf_camera* cam, const float* rays_o, int o_stride, const float* rays_d, int d_stride,
+                   int64_t n, float* rays, void* stream) {
+    if (!c || !cam || n < 0 || o_stride < 3 || d_stride < 3) {
+        set_error("nerf_pack_rays: invalid argument");
+        return NERF_E_INVALID;
+    }
+    if (n == 0) return NERF_OK;
+    if (!rays_o || !rays_d || !rays) {
+        set_error("nerf_pack_rays: NULL array");
+        return NERF_E_INVALID;
+    }
+    if (cam->ndc && (cam->H <= 0 || cam->W <= 0 || !(cam->ndc_focal > 0.0))) {
+        set_error("nerf_pack_rays: the NDC warp needs H, W and the focal length");
+        return NERF_E_INVALID;
+    }
+    DeviceGuard g(c->device);
+    HIP_TRY(launch_pack_rays(*cam, rays_o, o_stride, rays_d, d_stride, n, rays, (hipStream_t)stream));
+    return NERF_OK;
+}
+
 int nerf_render_frame(nerf_ctx* c, const nerf_frame_args* f) {
     if (!c || !f || f->first_pixel < 0 || f->n_pixels < 0) {
         set_error("nerf_render_frame: invalid argument");

@@ -53,13 +53,22 @@ __device__ __forceinline__ void bconv1(ConvTmp& t, PendingB& pd) {
     t.a0 = t.y0 * pd.sc;
     t.a1 = t.y1 * pd.sc;
 }
-template <int T, int Q>
+// BLK: the layout blocked by 32 points (MlpStore::blocked; mlp_kernel_h2.hip keep_pairs): a store instruction writes one
+// contiguous KiB - piece (T, Q) of the point group - with the nt bit
+template <int T, int Q, bool BLK>
 __device__ __forceinline__ void bkeep(const PendingB& pd, const f32x2& even, float y0, float y1) {
-    keep_quad<(32 * T + 8 * Q) * 4>(pd.keep_base, pd.keep_off, f32x4{even[0], even[1], y0, y1});
+    // (keep_base: the start of the ODD tile of the pair being converted, moved on in place by next_tile_pair - one scalar base
+    // and the signed immediate reach two tiles; a base per tile cost the forward kernel its last scalar registers)
+    if constexpr (BLK) keep_quad_nt<1024 * Q - ((T & 1) ? 0 : 4096)>(pd.keep_base, pd.keep_off, f32x4{even[0], even[1], y0, y1});
+    else keep_quad<(32 * T + 8 * Q) * 4>(pd.keep_base, pd.keep_off, f32x4{even[0], even[1], y0, y1});
 }
 
 // One k-tile against 8 output tiles; CONV >= 0: while the chunk runs, step s converts register pair s of pending tile CONV.
-template <int CONV, bool FIRST>
+template <bool BLK>
+__device__ __forceinline__ void next_tile_pair(PendingB& pd) {
+    if constexpr (BLK) pd.keep_base += 2048;
+}
+template <int CONV, bool FIRST, bool BLK>
 __device__ __forceinline__ void chunk_bwd(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x, XT (&hid)[8],
                                           const f32x16 (&pend)[8], PendingB& pd) {
     constexpr int C0 = CONV < 0 ? 0 : CONV;
@@ -72,7 +81,7 @@ __device__ __forceinline__ void chunk_bwd(PipeH& p, Frag4& cur, f32x16 (&acc)[8]
             if constexpr (pt == 11) {
                 bconv0<C0, s>(t, pend[C0], pd);
                 if constexpr ((s & 1) == 0) even = f32x2{t.y0, t.y1};
-                else bkeep<C0, (s >> 1)>(pd, even, t.y0, t.y1);
+                else bkeep<C0, (s >> 1), BLK>(pd, even, t.y0, t.y1);
             } else if constexpr (pt == 12) bconv1(t, pd);
             else if constexpr (pt == 13) conv_slice2<s>(hid[C0], t);
         }
@@ -80,29 +89,30 @@ __device__ __forceinline__ void chunk_bwd(PipeH& p, Frag4& cur, f32x16 (&acc)[8]
 }
 
 // a whole tile in the open (tile 0 at the start of a layer; every tile of d z_0, which nothing follows)
-template <int T, int S, bool SPLIT>
+template <int T, int S, bool SPLIT, bool BLK>
 __device__ __forceinline__ void bconvert_pairs(XT& dst, const f32x16& src, PendingB& pd, f32x2& even) {
     if constexpr (S < 8) {
         ConvTmp t;
         bconv0<T, S>(t, src, pd);
         if constexpr ((S & 1) == 0) even = f32x2{t.y0, t.y1};
-        else bkeep<T, (S >> 1)>(pd, even, t.y0, t.y1);
+        else bkeep<T, (S >> 1), BLK>(pd, even, t.y0, t.y1);
         if constexpr (SPLIT) {
             bconv1(t, pd);
             conv_slice2<S>(dst, t);
         }
-        bconvert_pairs<T, S + 1, SPLIT>(dst, src, pd, even);
+        bconvert_pairs<T, S + 1, SPLIT, BLK>(dst, src, pd, even);
     }
 }
-template <int T, bool SPLIT>
+template <int T, bool SPLIT, bool BLK>
 __device__ __forceinline__ void bconvert_tile(XT& dst, const f32x16& src, PendingB& pd) {
     f32x2 even;
-    bconvert_pairs<T, 0, SPLIT>(dst, src, pd, even);
+    bconvert_pairs<T, 0, SPLIT, BLK>(dst, src, pd, even);
 }
 
 constexpr int kPreSlotBytes = 1024;      // one 16-byte record per lane
 constexpr int kRgbRowFloats = 12 * kBiasTileFloats;
 
+template <bool BLK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
     extern __shared__ __attribute__((aligned(16))) char ring_lds[];
@@ -185,7 +195,9 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
             dsig_h0 = h == 0 ? dr[3] : 0.0f;
             f32x16 g[4];
             float m = 0.0f;
-            const unsigned off = 4u * ((unsigned)pt * (unsigned)b.out.hv_ld + 4u * (unsigned)h);
+            // (blocked: 16 KiB per point group of this 128-wide buffer)
+            const unsigned off = BLK ? ((unsigned)pt >> 5) * 16384u + ((unsigned)pt & 31u) * 32u + (unsigned)h * 16u
+                                     : 4u * ((unsigned)pt * (unsigned)b.out.hv_ld + 4u * (unsigned)h);
             Tile16 w0 = lds_tile_issue(rgb0), w1 = lds_tile_issue(rgb0 + 128 * 4), w2 = lds_tile_issue(rgb0 + 128 * 8);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -208,10 +220,16 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 v = {g[t][4 * q], g[t][4 * q + 1], g[t][4 * q + 2], g[t][4 * q + 3]};
-                    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1"
-                                 :
-                                 : "v"(off + (unsigned)((32 * t + 8 * q) * 4)), "v"(v), "s"(b.out.hv)
-                                 : "memory");
+                    if constexpr (BLK)
+                        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1"
+                                     :
+                                     : "v"(off + (unsigned)((4 * t + q) * 1024)), "v"(v), "s"(b.out.hv)
+                                     : "memory");
+                    else
+                        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1"
+                                     :
+                                     : "v"(off + (unsigned)((32 * t + 8 * q) * 4)), "v"(v), "s"(b.out.hv)
+                                     : "memory");
                 }
             }
             m_prev = half_max(m);
@@ -241,18 +259,14 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
             pd.m = 0.0f;
             if (bl == 0) {
                 pd.mask = u32x4{~0u, ~0u, ~0u, ~0u};
-                pd.keep_base = wave_uniform(b.out.feat);
+                pd.keep_base = wave_uniform(b.out.feat) + (BLK ? 1024 : 0);
                 pd.keep_off = 4u * ((unsigned)pt * (unsigned)b.out.feat_ld + 4u * (unsigned)h);
-#ifdef NERF_EXP_STORE_BLOCKED
-                pd.keep_off = 4u * (((unsigned)pt >> 5) * 32u * (unsigned)b.out.feat_ld + ((unsigned)pt & 31u) * 8u + (unsigned)h * 4u);
-#endif
+                if constexpr (BLK) pd.keep_off = ((unsigned)pt >> 5) * 32768u + ((unsigned)pt & 31u) * 32u + (unsigned)h * 16u;
             } else {
                 pd.mask = u32x4{__float_as_uint(mk[0]), __float_as_uint(mk[1]), __float_as_uint(mk[2]), __float_as_uint(mk[3])};
-                pd.keep_base = wave_uniform(b.out.h[D - bl]);
+                pd.keep_base = wave_uniform(b.out.h[D - bl]) + (BLK ? 1024 : 0);
                 pd.keep_off = 4u * ((unsigned)pt * (unsigned)b.out.h_ld[D - bl] + 4u * (unsigned)h);
-#ifdef NERF_EXP_STORE_BLOCKED
-                pd.keep_off = 4u * (((unsigned)pt >> 5) * 32u * (unsigned)b.out.h_ld[D - bl] + ((unsigned)pt & 31u) * 8u + (unsigned)h * 4u);
-#endif
+                if constexpr (BLK) pd.keep_off = ((unsigned)pt >> 5) * 32768u + ((unsigned)pt & 31u) * 32u + (unsigned)h * 16u;
             }
         };
         auto close_pending = [&](int slot) {
@@ -273,10 +287,10 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
         };
 
         // ---- d feature = W_views[:, :W]^T d(view pre-activation): four k-tiles, nothing pending yet ----
-        chunk_bwd<-1, true>(pipe, cur, accA, hid[0], hid, accB, pd);
-        chunk_bwd<-1, false>(pipe, cur, accA, hid[1], hid, accB, pd);
-        chunk_bwd<-1, false>(pipe, cur, accA, hid[2], hid, accB, pd);
-        chunk_bwd<-1, false>(pipe, cur, accA, hid[3], hid, accB, pd);
+        chunk_bwd<-1, true, BLK>(pipe, cur, accA, hid[0], hid, accB, pd);
+        chunk_bwd<-1, false, BLK>(pipe, cur, accA, hid[1], hid, accB, pd);
+        chunk_bwd<-1, false, BLK>(pipe, cur, accA, hid[2], hid, accB, pd);
+        chunk_bwd<-1, false, BLK>(pipe, cur, accA, hid[3], hid, accB, pd);
         make_pending(0, m_prev, pd.t_out);
         // the alpha column's operand: d sigma as value 0 of half-wave 0 (the column k = 0 of its k-tile), at d feature's scale
         XT xs;
@@ -289,23 +303,26 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
         // ---- backward layers 1 .. D: layer bl accumulates into `out` while the pending layer bl - 1 is converted ----
         auto layer_pass = [&](f32x16 (&pend)[8], f32x16 (&out)[8], int bl_) {
             const int bl = __builtin_amdgcn_readfirstlane(bl_);
-            bconvert_tile<0, true>(hid[0], pend[0], pd);
+            bconvert_tile<0, true, BLK>(hid[0], pend[0], pd);
             // this layer's outputs will want their ReLU mask at its end: trunk layer D - bl's, requested now
             fetch(mask_rec(b.fwd.mask[D - bl], pt), 2);
             if (bl == D) {      // the last layer: the next tile's records (their slots were read in this tile's prologue)
                 fetch(b.d_raw + pt_next * 4, 0);
                 fetch(mask_rec(b.fwd.mask_hv, pt_next), 1);
             }
-            chunk_bwd<1, true>(pipe, cur, out, hid[0], hid, pend, pd);
-            chunk_bwd<2, false>(pipe, cur, out, hid[1], hid, pend, pd);
-            chunk_bwd<3, false>(pipe, cur, out, hid[2], hid, pend, pd);
-            chunk_bwd<4, false>(pipe, cur, out, hid[3], hid, pend, pd);
-            chunk_bwd<5, false>(pipe, cur, out, hid[4], hid, pend, pd);
-            chunk_bwd<6, false>(pipe, cur, out, hid[5], hid, pend, pd);
-            chunk_bwd<7, false>(pipe, cur, out, hid[6], hid, pend, pd);
-            chunk_bwd<-1, false>(pipe, cur, out, hid[7], hid, pend, pd);
+            chunk_bwd<1, true, BLK>(pipe, cur, out, hid[0], hid, pend, pd);
+            next_tile_pair<BLK>(pd);
+            chunk_bwd<2, false, BLK>(pipe, cur, out, hid[1], hid, pend, pd);
+            chunk_bwd<3, false, BLK>(pipe, cur, out, hid[2], hid, pend, pd);
+            next_tile_pair<BLK>(pd);
+            chunk_bwd<4, false, BLK>(pipe, cur, out, hid[3], hid, pend, pd);
+            chunk_bwd<5, false, BLK>(pipe, cur, out, hid[4], hid, pend, pd);
+            next_tile_pair<BLK>(pd);
+            chunk_bwd<6, false, BLK>(pipe, cur, out, hid[5], hid, pend, pd);
+            chunk_bwd<7, false, BLK>(pipe, cur, out, hid[6], hid, pend, pd);
+            chunk_bwd<-1, false, BLK>(pipe, cur, out, hid[7], hid, pend, pd);
             close_pending(bl == 1 ? kBwdMaxFeat : D - bl + 1);      // (pending: d feature, then d z_{D - bl + 1})
-            if (bl == 1) chunk_bwd<-1, false>(pipe, cur, out, xs, hid, pend, pd);      // + w_alpha d sigma (nerf.py:86)
+            if (bl == 1) chunk_bwd<-1, false, BLK>(pipe, cur, out, xs, hid, pend, pd);      // + w_alpha d sigma (nerf.py:86)
             make_pending(bl, m_prev, pd.t_out);
         };
         int bl = 1;
@@ -324,15 +341,18 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
             for (int t = 0; t < 8; ++t) accA[t] = accB[t];
         }
         // ---- d z_0: nothing follows to hide behind ----
-        pd.keep_base = wave_uniform(b.out.h[0]);      // (what make_pending(D) chose, as a value hipcc keeps in scalar registers)
-        bconvert_tile<0, false>(hid[0], accA[0], pd);
-        bconvert_tile<1, false>(hid[0], accA[1], pd);
-        bconvert_tile<2, false>(hid[0], accA[2], pd);
-        bconvert_tile<3, false>(hid[0], accA[3], pd);
-        bconvert_tile<4, false>(hid[0], accA[4], pd);
-        bconvert_tile<5, false>(hid[0], accA[5], pd);
-        bconvert_tile<6, false>(hid[0], accA[6], pd);
-        bconvert_tile<7, false>(hid[0], accA[7], pd);
+        pd.keep_base = wave_uniform(b.out.h[0]) + (BLK ? 1024 : 0);      // (what make_pending(D) chose, as a value hipcc keeps in scalar registers)
+        bconvert_tile<0, false, BLK>(hid[0], accA[0], pd);
+        bconvert_tile<1, false, BLK>(hid[0], accA[1], pd);
+        next_tile_pair<BLK>(pd);
+        bconvert_tile<2, false, BLK>(hid[0], accA[2], pd);
+        bconvert_tile<3, false, BLK>(hid[0], accA[3], pd);
+        next_tile_pair<BLK>(pd);
+        bconvert_tile<4, false, BLK>(hid[0], accA[4], pd);
+        bconvert_tile<5, false, BLK>(hid[0], accA[5], pd);
+        next_tile_pair<BLK>(pd);
+        bconvert_tile<6, false, BLK>(hid[0], accA[6], pd);
+        bconvert_tile<7, false, BLK>(hid[0], accA[7], pd);
     }   // tile loop
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -368,13 +388,16 @@ hipError_t launch_mlp_bwd_h2(const MlpBwdLaunch& b, hipStream_t s) {
     }
     const dim3 grid((unsigned)(tiles < n_cu[dev] ? tiles : n_cu[dev])), block(256);
     const size_t lds = kRingH * kChunkBytes;
-    static bool raised[64] = {};
-    if (!raised[dev]) {
-        e = hipFuncSetAttribute((const void*)nerf_mlp_bwd_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool raised[64][2] = {};
+    const int blk = b.out.blocked ? 1 : 0;
+    if (!raised[dev][blk]) {
+        e = hipFuncSetAttribute(blk ? (const void*)nerf_mlp_bwd_h2_kernel<true> : (const void*)nerf_mlp_bwd_h2_kernel<false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        raised[dev] = true;
+        raised[dev][blk] = true;
     }
-    hipLaunchKernelGGL(nerf_mlp_bwd_h2_kernel, grid, block, lds, s, b);
+    if (blk) hipLaunchKernelGGL(nerf_mlp_bwd_h2_kernel<true>, grid, block, lds, s, b);
+    else hipLaunchKernelGGL(nerf_mlp_bwd_h2_kernel<false>, grid, block, lds, s, b);
     return hipGetLastError();
 }
 

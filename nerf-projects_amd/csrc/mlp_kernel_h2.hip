@@ -83,26 +83,46 @@ __device__ __forceinline__ void keep_pair(const Pending& pd, float y0, float y1)
                  : "memory");
 }
 // two pairs (a register quad: four consecutive features) in one 16-byte store: half the instructions and half the write
-// requests of keep_pair
-template <int T, int Q>
+// requests of keep_pair.
+// STORE = 1: row-major [points, channels]: the 16 bytes at (point, feature 32 T + 8 Q + 4 h): a store instruction covers 32
+// rows x 32 bytes - partial lines, completed by the three other quads of the tile steps later.
+// STORE = 2: BLOCKED by 32 points (MlpStore::blocked): the buffer is [point / 32][tile T][quad Q][32 points][2 half-waves]
+// [4 features], so the instruction writes ONE contiguous KiB - eight whole lines - and carries the nt bit (written once, read
+// once by the weight-gradient kernel after gigabytes of other traffic: it need not displace the weight stream from L2).
+// keep_off is the lane's place inside a piece; keep_base points at the start of the ODD tile of the pair being converted, so
+// that the signed 13-bit immediate reaches both tiles (1024 Q - 4096 for the even one), and moves on by two tiles when the odd
+// one is done (next_tile_pair: two scalar adds in place - a base per tile spilled scalar registers into vector ones and those
+// into scratch, which tools/audit_lds_waits.py and the no-scratch rule of tests/test_kernel_audit.py both refuse).
+// Measured with a timing-only build before any consumer could read the layout (profiles/r04_store_layout_ab.txt): forward
+// 1.36 -> 0.93 ms per iteration, backward-data 1.01 -> 0.69; the nt bit on the row-major form DOUBLES both (partial lines
+// written through).
+template <int T, int Q, int STORE>
 __device__ __forceinline__ void keep_pairs(const Pending& pd, const f32x2& even, float y0, float y1) {
     const f32x4 v = {even[0], even[1], y0, y1};
 #ifdef NERF_EXP_NOSTORE      // timing experiments (profiles/r02_kernel_ab.md)
     asm volatile("" ::"v"(v));
     return;
 #endif
-#ifdef NERF_EXP_STORE_BLOCKED
-    asm volatile("global_store_dwordx4 %0, %1, %2" NERF_STORE_POLICY "\n\ts_nop 1" : : "v"(pd.keep_off + (8u * T + 2u * Q) * 512u), "v"(v), "s"(pd.keep_base) : "memory");
-    return;
-#endif
     // (s_nop 1: a store of more than 8 bytes reads its data registers late - two wait states before a vector instruction
     // may overwrite them on gfx950; hipcc's hazard recogniser does not look inside inline asm)
-    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" NERF_STORE_POLICY "\n\ts_nop 1"
-                 :
-                 : "v"(pd.keep_off), "v"(v), "s"(pd.keep_base), "n"((32 * T + 8 * Q) * 4)
-                 : "memory");
+    if constexpr (STORE == 2) {
+        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1"
+                     :
+                     : "v"(pd.keep_off), "v"(v), "s"(pd.keep_base), "n"(1024 * Q - ((T & 1) ? 0 : 4096))
+                     : "memory");
+    } else {
+        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1"
+                     :
+                     : "v"(pd.keep_off), "v"(v), "s"(pd.keep_base), "n"((32 * T + 8 * Q) * 4)
+                     : "memory");
+    }
 }
-template <int P, bool STORE = false, int T = 0>
+// blocked stores: tiles 2 k, 2 k + 1 are done, the base moves to the next pair's odd tile
+template <int STORE>
+__device__ __forceinline__ void next_tile_pair(Pending& pd) {
+    if constexpr (STORE == 2) pd.keep_base += 2048;
+}
+template <int P, int STORE = 0, int T = 0>
 __device__ __forceinline__ void convert_pair(XT& dst, const f32x16& src, Pending& pd, const f32x2& b) {
 #ifdef NERF_ABLATE_CONV
     if (P == 0) dst.hi[0][0] = __float_as_uint(src[0] + b[0]);
@@ -112,7 +132,7 @@ __device__ __forceinline__ void convert_pair(XT& dst, const f32x16& src, Pending
     const float y1 = fmaxf(fmaf(src[2 * P + 1], pd.c, b[1]), pd.floor);
     if constexpr (STORE) {
         if constexpr ((P & 1) == 0) pd.even = f32x2{y0, y1};
-        else keep_pairs<T, (P >> 1)>(pd, pd.even, y0, y1);
+        else keep_pairs<T, (P >> 1), STORE>(pd, pd.even, y0, y1);
     }
     pd.m = fmaxf(fmaxf(pd.m, fabsf(y0)), fabsf(y1));
     const float a0 = y0 * pd.sc, a1 = y1 * pd.sc;
@@ -135,14 +155,14 @@ __device__ __forceinline__ void convert_pair(XT& dst, const f32x16& src, Pending
 }
 
 // a whole tile at once (not hidden: tile 0 at the start of a layer)
-template <int P, bool STORE = false, int T = 0>
+template <int P, int STORE = 0, int T = 0>
 __device__ __forceinline__ void convert_pairs(XT& dst, const f32x16& src, Pending& pd, const Tile16& b) {
     if constexpr (P < 8) {
         convert_pair<P, STORE, T>(dst, src, pd, f32x2{b.q[P >> 1][2 * (P & 1)], b.q[P >> 1][2 * (P & 1) + 1]});
         convert_pairs<P + 1, STORE, T>(dst, src, pd, b);
     }
 }
-template <int T, bool STORE = false>
+template <int T, int STORE = 0>
 __device__ __forceinline__ void convert_tile(XT& dst, const f32x16& src, Pending& pd) {
     Tile16 b = lds_tile_issue(pd.bias_addr + 128 * T);
     lds_tile_wait(b);
@@ -151,7 +171,7 @@ __device__ __forceinline__ void convert_tile(XT& dst, const f32x16& src, Pending
 // tile 0 with its bias entries already fetched by make_pending, together with its scale-table row: the two LDS latencies
 // of a layer boundary overlap instead of adding up (-0.5 % per launch). Requested earlier still - before the layer's last
 // chunk - hipcc parks the in-flight destination registers in AGPRs (tools/audit_lds_waits.py rejects the build).
-template <bool STORE = false>
+template <int STORE = 0>
 __device__ __forceinline__ void convert_tile0_with(XT& dst, const f32x16& src, Pending& pd, Tile16& b) {
     convert_pairs<0, STORE, 0>(dst, src, pd, b);
 }
@@ -177,7 +197,7 @@ __device__ __forceinline__ void conv_slice1(ConvTmp& t, Pending& pd) {
 // chunk kinds (group order: pack_weights.cpp, each unit of four groups re-cut into [k-slice][hi|lo] by
 // convert_stream_h2 below). CONV >= 0: while the chunk runs, step s converts register pair s of pending tile CONV;
 // its two bias entries are requested one step earlier.
-template <int CONV, bool FIRST, bool STORE = false>
+template <int CONV, bool FIRST, int STORE = 0>
 __device__ __forceinline__ void chunk_ktile8(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x, XT (&hid)[8],
                                              const f32x16 (&pend)[8], Pending& pd) {
     constexpr int C0 = CONV < 0 ? 0 : CONV;
@@ -193,7 +213,7 @@ __device__ __forceinline__ void chunk_ktile8(PipeH& p, Frag4& cur, f32x16 (&acc)
                 conv_slice0<s>(t, pend[C0], pd, r);
                 if constexpr (STORE) {
                     if constexpr ((s & 1) == 0) even = f32x2{t.y0, t.y1};
-                    else keep_pairs<C0, (s >> 1)>(pd, even, t.y0, t.y1);
+                    else keep_pairs<C0, (s >> 1), STORE>(pd, even, t.y0, t.y1);
                 }
             } else if constexpr (pt == 12) conv_slice1(t, pd);
             else if constexpr (pt == 13) conv_slice2<s>(hid[C0], t);
@@ -218,7 +238,7 @@ __device__ __forceinline__ void chunk_ktile4(PipeH& p, Frag4& cur, f32x16 (&acc)
         if constexpr (pt < 6) mma_one<pt, false>(acc[s], f, x);
     });
 }
-template <int CONV, bool FIRST, bool STORE = false>
+template <int CONV, bool FIRST, int STORE = 0>
 __device__ __forceinline__ void chunk_pair4(PipeH& p, Frag4& cur, f32x16 (&acc)[8], const XT& x0, const XT& x1,
                                             XT (&hid)[8], const f32x16 (&pend)[8], Pending& pd) {
     constexpr int C0 = CONV < 0 ? 0 : CONV;
@@ -243,8 +263,8 @@ __device__ __forceinline__ void chunk_pair4(PipeH& p, Frag4& cur, f32x16 (&acc)[
                         even0 = f32x2{t0.y0, t0.y1};
                         even1 = f32x2{t1.y0, t1.y1};
                     } else {
-                        keep_pairs<C0, (s >> 1)>(pd, even0, t0.y0, t0.y1);
-                        keep_pairs<C0 + 1, (s >> 1)>(pd, even1, t1.y0, t1.y1);
+                        keep_pairs<C0, (s >> 1), STORE>(pd, even0, t0.y0, t0.y1);
+                        keep_pairs<C0 + 1, (s >> 1), STORE>(pd, even1, t1.y0, t1.y1);
                     }
                 }
             } else if constexpr (pt == 12) {
@@ -329,7 +349,7 @@ __device__ __forceinline__ float row_dot4(const f32x16 (&x)[4], unsigned w_addr)
 // STORE: the training forward pass - also writes what autograd would keep (MlpLaunch::st: every trunk layer's post-ReLU
 // output, the feature vector, the view layer's output), each value as it leaves conv_slice0 / convert_pair / finish_views.
 // The stream it is given is the PLAIN network's (no row equalisation): the kept activations are the reference's.
-template <int MODE, bool STORE = false>
+template <int MODE, int STORE = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void nerf_mlp_h2_kernel(const MlpLaunch a) {
     // The ring is the dynamic LDS allocation; the bias block and the small per-layer tables are static.
@@ -352,7 +372,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
     }
     prefetch_pieces<0, 4>(piece_src(pipe, 2), piece_dst(pipe, 2));   // chunk 0's first-half steps issue the other four
     for (int i = threadIdx.x; i < a.n_bias_tiles * kBiasTileFloats; i += 256) bias_lds[i] = a.bias[i];
-    if (STORE && threadIdx.x < kBwdMaxSlots) max_record[threadIdx.x] = 0u;
+    if (STORE != 0 && threadIdx.x < kBwdMaxSlots) max_record[threadIdx.x] = 0u;
     if (threadIdx.x < a.D + 3) {
         const int l = threadIdx.x;
         const bool has_gain = l <= (a.use_viewdirs ? a.D : a.D - 1);
@@ -446,17 +466,10 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
                 pd.maskw = 0u;
                 pd.mask_base = wave_uniform(is_feature ? a.st.mask_hv : a.st.mask[l]);      // (feature_linear: not written)
                 pd.mask_off = 16u * (2u * (unsigned)pt + (unsigned)h);
-                pd.keep_base = is_feature ? a.st.feat : a.st.h[l];
+                pd.keep_base = (is_feature ? a.st.feat : a.st.h[l]) + (STORE == 2 ? 1024 : 0);      // (blocked: keep_pairs)
                 pd.keep_off = 4u * ((unsigned)pt * (unsigned)(is_feature ? a.st.feat_ld : a.st.h_ld[l]) + 4u * (unsigned)h);
-#ifdef NERF_EXP_STORE_BLOCKED  // timing experiment (results are NOT what the backward pass expects): layout blocked by 32 points
-                {
-                    const unsigned ld = (unsigned)(is_feature ? a.st.feat_ld : a.st.h_ld[l]);
-                    pd.keep_off = 4u * (((unsigned)pt >> 5) * 32u * ld + ((unsigned)pt & 31u) * 4u + (unsigned)h * 128u);
-                }
-#endif
-#ifdef NERF_EXP_STORE_SMALL  // timing experiment: every wave writes the same few KiB (no write traffic to speak of)
-                pd.keep_off = (unsigned)lane * 16u + (unsigned)wave * 4096u;
-#endif
+                if constexpr (STORE == 2)      // blocked by 32 points: 32 KiB per group of a 256-wide buffer, 32 bytes per point of a piece
+                    pd.keep_off = ((unsigned)pt >> 5) * 32768u + ((unsigned)pt & 31u) * 32u + (unsigned)h * 16u;
             }
         };
         // all 8 tiles of the pending layer are converted: its true output range
@@ -486,10 +499,13 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
         auto layer_pass = [&](f32x16 (&pend)[8], f32x16 (&out)[8], int l) {
             convert_tile0_with<STORE>(hid[0], pend[0], pd, bias0_req);
             chunk_ktile8<1, true, STORE>(pipe, cur, out, hid[0], hid, pend, pd);
+            next_tile_pair<STORE>(pd);
             chunk_ktile8<2, false, STORE>(pipe, cur, out, hid[1], hid, pend, pd);
             chunk_ktile8<3, false, STORE>(pipe, cur, out, hid[2], hid, pend, pd);
+            next_tile_pair<STORE>(pd);
             chunk_ktile8<4, false, STORE>(pipe, cur, out, hid[3], hid, pend, pd);
             chunk_ktile8<5, false, STORE>(pipe, cur, out, hid[4], hid, pend, pd);
+            next_tile_pair<STORE>(pd);
             chunk_ktile8<6, false, STORE>(pipe, cur, out, hid[5], hid, pend, pd);
             chunk_ktile8<7, false, STORE>(pipe, cur, out, hid[6], hid, pend, pd);
             chunk_ktile8<-1, false>(pipe, cur, out, hid[7], hid, pend, pd);
@@ -536,8 +552,11 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             // feature_linear
             convert_tile0_with<STORE>(hid[0], accA[0], pd, bias0_req);
             convert_tile<1, STORE>(hid[1], accA[1], pd);
+            next_tile_pair<STORE>(pd);
             chunk_pair4<2, true, STORE>(pipe, cur, accB, hid[0], hid[1], hid, accA, pd);
+            next_tile_pair<STORE>(pd);
             chunk_pair4<4, false, STORE>(pipe, cur, accB, hid[2], hid[3], hid, accA, pd);
+            next_tile_pair<STORE>(pd);
             chunk_pair4<6, false, STORE>(pipe, cur, accB, hid[4], hid[5], hid, accA, pd);
             chunk_pair4<-1, false>(pipe, cur, accB, hid[6], hid[7], hid, accA, pd);
             close_pending(kBwdMaxFeatValue);
@@ -651,14 +670,16 @@ hipError_t launch_mlp_h2(const MlpLaunch& a, int mode, hipStream_t s) {
         rows_ok = rows_ok && a.st.maxes && a.st.mask_hv && (uint64_t)a.n_points * 32u < ((uint64_t)1 << 32);
         for (int i = 0; i < a.D; ++i) rows_ok = rows_ok && a.st.mask[i] && (reinterpret_cast<uintptr_t>(a.st.mask[i]) & 15) == 0;
         if (!rows_ok) return hipErrorInvalidValue;
-        static bool raised_store[64] = {};
-        if (!raised_store[dev]) {
-            e = hipFuncSetAttribute((const void*)nerf_mlp_h2_kernel<kInputRays, true>,
+        static bool raised_store[64][2] = {};
+        const int blk = a.st.blocked ? 1 : 0;
+        if (!raised_store[dev][blk]) {
+            e = hipFuncSetAttribute(blk ? (const void*)nerf_mlp_h2_kernel<kInputRays, 2> : (const void*)nerf_mlp_h2_kernel<kInputRays, 1>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            raised_store[dev] = true;
+            raised_store[dev][blk] = true;
         }
-        hipLaunchKernelGGL((nerf_mlp_h2_kernel<kInputRays, true>), grid, block, lds, s, a);
+        if (blk) hipLaunchKernelGGL((nerf_mlp_h2_kernel<kInputRays, 2>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((nerf_mlp_h2_kernel<kInputRays, 1>), grid, block, lds, s, a);
         return hipGetLastError();
     }
     if (!raised[dev][mode]) {

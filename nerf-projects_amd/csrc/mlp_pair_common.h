@@ -445,19 +445,14 @@ __device__ __forceinline__ void flush_maxes(unsigned* global_slots, const unsign
 // lane, the rest an immediate (the launchers bound the buffers). (s_nop 1: a store of more than 8 bytes reads its data
 // registers late - two wait states before a vector instruction may overwrite them on gfx950; hipcc's hazard recogniser
 // does not look inside inline asm.)
-// NERF_STORE_POLICY: the cache-policy bits of these stores (timing experiments: -DNERF_EXP_STORE_NT)
-#ifdef NERF_EXP_STORE_NT
-#define NERF_STORE_POLICY " nt"
-#else
-#define NERF_STORE_POLICY ""
-#endif
 template <int IMM>
 __device__ __forceinline__ void keep_quad(float* base, unsigned off, const f32x4& v) {
-#ifdef NERF_EXP_STORE_BLOCKED      // timing experiment (results are NOT what the consumers expect): pieces of 32 points x 8 features
-    asm volatile("global_store_dwordx4 %0, %1, %2" NERF_STORE_POLICY "\n\ts_nop 1" : : "v"(off + (unsigned)(IMM / 32) * 1024u), "v"(v), "s"(base) : "memory");
-    return;
-#endif
-    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" NERF_STORE_POLICY "\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base), "n"(IMM) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base), "n"(IMM) : "memory");
+}
+// the same with the nt bit, for stores that write whole lines of data nobody reads soon (the layout blocked by 32 points)
+template <int IMM>
+__device__ __forceinline__ void keep_quad_nt(float* base, unsigned off, const f32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base), "n"(IMM) : "memory");
 }
 template <int IMM>
 __device__ __forceinline__ void keep_word(unsigned* base, unsigned off, unsigned v) {

@@ -139,6 +139,12 @@ struct MlpStore {
     // 2s + 1 bit 31 - 8 (T & 1) - s (the order the conversion hooks meet them in). mask_hv: the view layer's, words 0, 1.
     unsigned* mask[kMaxDepth];
     unsigned* mask_hv;
+    // fp16-pair kernels only: h[i] / feat (forward) and h[i] / feat / hv (backward-data) are BLOCKED by 32 points instead of
+    // row-major: [point / 32][feature / 32][(feature / 8) % 4][point % 32][(feature / 4) % 2][feature % 4] - the 16 bytes a
+    // lane of those kernels holds per store instruction (its point, four consecutive features) laid out so that the
+    // instruction's 64 lanes write one contiguous KiB. A buffer has ceil(P / 32) groups of 32 x width floats; the forward
+    // pass's hv stays row-major. Consumers: grad_batch_pair_dma_kernel and grad_batch_kernel<1> (GradJob::blocked).
+    int blocked;
     // [kBwdMaxSlots] float bits of running maxima (see MlpBwdLaunch::maxes): the forward pass enters the kept activations'
     // (kBwdMaxKept + i) and the feature vector's (kBwdMaxFeatValue)
     unsigned* maxes;
@@ -274,6 +280,8 @@ hipError_t launch_sample_pdf(const float* bins, const float* weights, int w_ld, 
                              hipStream_t s);
 
 hipError_t launch_raygen(const nerf_camera& cam, int64_t first, int64_t n, float* rays, hipStream_t s);
+hipError_t launch_pack_rays(const nerf_camera& cam, const float* rays_o, int o_ld, const float* rays_d, int d_ld, int64_t n,
+                            float* rays, hipStream_t s);
 hipError_t launch_image_metrics(const float* a, const float* b, int H, int W, float max_val, float* tmp,
                                 double* partial, float* out, hipStream_t s);
 
@@ -332,6 +340,9 @@ struct GradJob {
     // index inside the Linear's input, scaled only inside [col_lo, col_hi): the hidden part of a concatenated input);
     // nullptr = 0.
     GradExps ex;
+    // bit 0: A (dY) is blocked by 32 points (MlpStore::blocked), bit 1: B (X) is, and its feature 0 is column b_first of the
+    // Linear's input (the hidden part of a concatenated input lives in a buffer of its own then)
+    int blocked, b_first;
     // (last, so that the positional initialisers of the other jobs leave them zero) grad_batch_pair_dma_kernel only: a ONE-ROW
     // Linear on the same input X - alpha_linear beside feature_linear (nerf.py:86,89) - rides along: y [P] (stride ldy) is its
     // dY, and its weight gradient sum_p y[p] X[p, :] is formed in fp32 from the X values the job has in registers anyway (a
@@ -365,6 +376,33 @@ hipError_t launch_grad_batch_with_rider(GradBatch& b, const GradRider& r, float*
 hipError_t launch_embed_train(const float* rays, int ray_ld, const float* z, int64_t P, int S, int Lx, int Lv,
                               float* x0, int ld0, float* x1, int ld1, float* vcat, int ldv, int voff, hipStream_t s);
 hipError_t launch_mse(const float* x, const float* t, int64_t n, float* grad, double* part, float* loss, hipStream_t s);
+// The fused small launches of the training step (train_kernels.hip): each evaluates the expressions of the stage kernels it
+// replaces, through the same device functions (ray_device.h)
+hipError_t launch_train_prologue(const float* rays, int ray_ld, int64_t N, int S, int lindisp, const float* t_rand, float* z,
+                                 int Lx, int Lv, float* x0, int ld0, float* x1, int ld1, float* vcat, int ldv, int voff,
+                                 unsigned* zero, int n_zero, hipStream_t s);
+hipError_t launch_train_mid(const float* raw, int C, const float* z_c, const float* rays_d, int d_ld, const float* noise,
+                            int white_bkgd, int64_t N, int S, float* rgb_c, float* w_c, const float* u, int n_samples,
+                            float* z_f, hipStream_t s);
+struct TrainEpilogue {
+    const float* rays_d; int d_ld;
+    const float* target;
+    int64_t N;
+    int white_bkgd;
+    // the last pass (the fine one, or the only one)
+    const float* raw_l; int C_l; const float* z_l; const float* noise_l; int S_l; float* d_raw_l;
+    // the coarse pass when a fine one follows it (raw_c = nullptr otherwise): its colours come from the mid launch
+    const float* raw_c; int C_c; const float* z_c; const float* noise_c; int S_c; float* d_raw_c; const float* rgb_c;
+    float* out_rgb;          // [N,3] the last pass's colours (the caller's buffer, or scratch)
+    float* out_rgb0;         // [N,3] optional copy of the coarse colours for the caller
+    double* part;            // [2][N] scratch
+    unsigned* ticket;        // zeroed before the launch
+    float* loss_dev;         // [2] scratch
+    float* out_loss;         // [2] optional (nerf_train_args::loss)
+    float* out_stats;        // [5] optional (nerf_train_args::stats)
+};
+hipError_t launch_train_epilogue(const TrainEpilogue& e, hipStream_t s);
+hipError_t launch_train_stats(const float* loss, bool two, float* stats, hipStream_t s);
 hipError_t launch_composite_bwd(const float* raw, int C, const float* z, const float* rays_d, int d_ld,
                                 const float* noise, int white_bkgd, int64_t N, int S, const float* g_rgb,
                                 float* d_raw, hipStream_t s);

@@ -10,45 +10,9 @@
 #include <math.h>
 
 #include "nerf_internal.h"
+#include "ray_device.h"
 
 namespace nerf {
-
-// torch.linspace(0, 1, S)[i] in fp32: both halves are a single fused multiply-add of the
-// fp32 step (checked bit-for-bit against torch 2.10, tests/golden/linspace.npz).
-__device__ __forceinline__ float linspace01(int i, int S) {
-    if (S <= 1) return 0.0f;
-    const float step = __fdiv_rn(1.0f, (float)(S - 1));
-    return i < S / 2 ? fmaf(step, (float)i, 0.0f) : fmaf(-step, (float)(S - 1 - i), 1.0f);
-}
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-// inclusive scans over the 64 lanes of a wavefront (Kogge-Stone on shuffles)
-__device__ __forceinline__ double wave_scan_mul(double v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double n = __shfl_up(v, o);
-        if (lane >= o) v *= n;
-    }
-    return v;
-}
-__device__ __forceinline__ double wave_scan_add(double v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double n = __shfl_up(v, o);
-        if (lane >= o) v += n;
-    }
-    return v;
-}
 
 // ---- R3: Embedder.embed (nerf/embedder.py:72-80) -----------------------------------------
 __global__ void embed_kernel(const float* __restrict__ x, int64_t n, int multires, float* __restrict__ out) {
@@ -76,15 +40,6 @@ hipError_t launch_embed(const float* x, int64_t n, int multires, float* out, hip
 }
 
 // ---- R2: stratified depths (nerf.ipynb:418-444) ------------------------------------------
-__device__ __forceinline__ float z_at(float near, float far, int i, int S, int lindisp) {
-    const float t = linspace01(i, S);
-    const float omt = __fsub_rn(1.0f, t);
-    if (!lindisp) return __fadd_rn(__fmul_rn(near, omt), __fmul_rn(far, t));            // :421
-    const float a = __fmul_rn(__fdiv_rn(1.0f, near), omt);
-    const float b = __fmul_rn(__fdiv_rn(1.0f, far), t);
-    return __fdiv_rn(1.0f, __fadd_rn(a, b));                                             // :424
-}
-
 __global__ void stratified_kernel(const float* __restrict__ rays, int ray_ld, int64_t N, int S, int lindisp,
                                   const float* __restrict__ t_rand, float* __restrict__ z_vals) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -92,15 +47,7 @@ __global__ void stratified_kernel(const float* __restrict__ rays, int ray_ld, in
     const int64_t ray = idx / S;
     const int i = (int)(idx - ray * S);
     const float near = rays[ray * ray_ld + 6], far = rays[ray * ray_ld + 7];
-    float z = z_at(near, far, i, S, lindisp);
-    if (t_rand) {                                                                         // :428-444
-        const float zl = i > 0 ? z_at(near, far, i - 1, S, lindisp) : z;
-        const float zu = i < S - 1 ? z_at(near, far, i + 1, S, lindisp) : z;
-        const float lower = i > 0 ? __fmul_rn(0.5f, __fadd_rn(z, zl)) : z;
-        const float upper = i < S - 1 ? __fmul_rn(0.5f, __fadd_rn(zu, z)) : z;
-        z = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), t_rand[idx]));
-    }
-    z_vals[idx] = z;
+    z_vals[idx] = stratified_z(near, far, i, S, lindisp, t_rand ? t_rand + idx : nullptr);
 }
 
 hipError_t launch_stratified(const float* rays, int ray_ld, int64_t N, int S, int lindisp, const float* t_rand,
@@ -122,71 +69,8 @@ __global__ __launch_bounds__(64) void composite_kernel(const float* __restrict__
                                                        float* __restrict__ rgb_map, float* __restrict__ disp_map,
                                                        float* __restrict__ acc_map, float* __restrict__ weights,
                                                        float* __restrict__ depth_map) {
-    const int64_t ray = blockIdx.x;
-    const int lane = threadIdx.x;
-    const float* d = rays_d + ray * d_ld;
-    const float dx = d[0], dy = d[1], dz = d[2];
-    const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));   // :305
-    const float* z = z_vals + ray * S;
-    const float* rw = raw + ray * (int64_t)S * C;
-
-    double carry = 1.0;   // prod of (1 - alpha + 1e-10) over all earlier samples
-    float sr = 0.0f, sg = 0.0f, sb = 0.0f, sd = 0.0f, sa = 0.0f;
-    for (int base = 0; base < S; base += 64) {
-        const int i = base + lane;
-        const bool on = i < S;
-        float alpha = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f, zi = 0.0f;
-        if (on) {
-            zi = z[i];
-            float dist = i < S - 1 ? __fsub_rn(z[i + 1], zi) : 1e10f;                   // :295-300
-            dist = __fmul_rn(dist, norm);
-            float sig = rw[(int64_t)i * C + 3];
-            if (noise) sig = __fadd_rn(sig, noise[ray * S + i]);                         // :328
-            sig = fmaxf(sig, 0.0f);
-            alpha = __fsub_rn(1.0f, expf(__fmul_rn(-sig, dist)));                        // :291
-            r = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw[(int64_t)i * C + 0])));        // :308 sigmoid
-            g = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw[(int64_t)i * C + 1])));
-            b = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw[(int64_t)i * C + 2])));
-        }
-        const double tf = on ? (double)__fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f) : 1.0;
-        const double incl = wave_scan_mul(tf, lane);
-        double excl = __shfl_up(incl, 1);
-        if (lane == 0) excl = 1.0;
-        const float T = (float)(carry * excl);                                           // exclusive cumprod (:329)
-        carry *= __shfl(incl, 63);
-        if (on) {
-            const float w = __fmul_rn(alpha, T);
-            if (weights) weights[ray * S + i] = w;
-            sr += __fmul_rn(w, r);
-            sg += __fmul_rn(w, g);
-            sb += __fmul_rn(w, b);
-            sd += __fmul_rn(w, zi);
-            sa += w;
-        }
-    }
-    sr = wave_sum(sr);                                                                    // :332
-    sg = wave_sum(sg);
-    sb = wave_sum(sb);
-    sd = wave_sum(sd);                                                                    // :335
-    sa = wave_sum(sa);                                                                    // :343
-    if (lane == 0) {
-        const float denom = fmaxf(1e-10f, sa);                                           // :339
-        const float disp = __fdiv_rn(1.0f, fmaxf(__fdiv_rn(sd, denom), 1e-10f));         // :340
-        if (white_bkgd) {                                                                 // :346-347
-            const float bg = __fsub_rn(1.0f, sa);
-            sr = __fadd_rn(sr, bg);
-            sg = __fadd_rn(sg, bg);
-            sb = __fadd_rn(sb, bg);
-        }
-        if (rgb_map) {
-            rgb_map[ray * 3 + 0] = sr;
-            rgb_map[ray * 3 + 1] = sg;
-            rgb_map[ray * 3 + 2] = sb;
-        }
-        if (disp_map) disp_map[ray] = disp;
-        if (acc_map) acc_map[ray] = sa;
-        if (depth_map) depth_map[ray] = sd;
-    }
+    composite_ray(blockIdx.x, threadIdx.x, raw, C, z_vals, rays_d, d_ld, noise, white_bkgd, S, rgb_map, disp_map, acc_map,
+                  weights, depth_map);
 }
 
 hipError_t launch_composite(const float* raw, int C, const float* z, const float* rays_d, int d_ld,
@@ -208,90 +92,8 @@ __global__ __launch_bounds__(64) void sample_pdf_kernel(const float* __restrict_
                                                         int n_sort, float* __restrict__ samples_out,
                                                         float* __restrict__ z_merged, float* __restrict__ z_std) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* cdf = (float*)smem;
-    float* bins = cdf + M;
-    float* zall = bins + M;
-    const int64_t ray = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int S = M + 1;   // coarse samples when bins are the mid-points
-    const int nb = M - 1;  // number of pdf bins
-
-    // bins: given, or z_vals_mid = .5*(z[1:] + z[:-1]) (nerf.ipynb:460)
-    for (int i = lane; i < M; i += 64)
-        bins[i] = bins_in ? bins_in[ray * M + i]
-                          : __fmul_rn(0.5f, __fadd_rn(z_coarse[ray * S + i + 1], z_coarse[ray * S + i]));
-
-    // weights + 1e-5, pdf = w / sum(w) (nerf_helpers.py:396-397)
-    const float* w = weights + ray * w_ld + w_off;
-    float part = 0.0f;
-    for (int i = lane; i < nb; i += 64) part += __fadd_rn(w[i], 1e-5f);
-    const float total = wave_sum(part);
-
-    // cdf = cat[0, cumsum(pdf)] (:398-400), prefixes accumulated in fp64 and rounded to fp32
-    double carry = 0.0;
-    if (lane == 0) cdf[0] = 0.0f;
-    for (int base = 0; base < nb; base += 64) {
-        const int i = base + lane;
-        const double pdf = i < nb ? (double)__fdiv_rn(__fadd_rn(w[i], 1e-5f), total) : 0.0;
-        const double incl = wave_scan_add(pdf, lane);
-        if (i < nb) cdf[i + 1] = (float)(carry + incl);
-        carry += __shfl(incl, 63);
-    }
-    __syncthreads();
-
-    double sum = 0.0;
-    for (int j = lane; j < n_samples; j += 64) {
-        const float u = u_in ? u_in[ray * n_samples + j] : linspace01(j, n_samples);      // :404-407
-        // searchsorted(cdf, u, right=True): first index with cdf[idx] > u (:423)
-        int lo = 0, hi = M;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
-        }
-        const int below = max(0, lo - 1), above = min(M - 1, lo);                         // :424-425
-        const float c0 = cdf[below], c1 = cdf[above], b0 = bins[below], b1 = bins[above];
-        float denom = __fsub_rn(c1, c0);                                                  // :434
-        if (denom < 1e-5f) denom = 1.0f;                                                  // :435
-        const float t = __fdiv_rn(__fsub_rn(u, c0), denom);                               // :436
-        const float smp = __fadd_rn(b0, __fmul_rn(t, __fsub_rn(b1, b0)));                 // :437
-        if (samples_out) samples_out[ray * n_samples + j] = smp;
-        if (z_merged) zall[S + j] = smp;
-        sum += (double)smp;
-    }
-    if (z_std) {
-        // torch.std(z_samples, unbiased=False) (nerf.ipynb:486); ATen accumulates in fp64
-        const double mean = wave_sum(sum) / (double)n_samples;
-        double m2 = 0.0;
-        __syncthreads();
-        for (int j = lane; j < n_samples; j += 64) {
-            const double dv = (double)(z_merged ? zall[S + j] : samples_out[ray * n_samples + j]) - mean;
-            m2 += dv * dv;
-        }
-        m2 = wave_sum(m2);
-        if (lane == 0) z_std[ray] = (float)sqrt(m2 / (double)n_samples);
-    }
-    if (!z_merged) return;
-
-    // z_vals = sort(cat[z_vals, z_samples]) (nerf.ipynb:467): bitonic network in LDS, padded with +inf
-    for (int i = lane; i < S; i += 64) zall[i] = z_coarse[ray * S + i];
-    for (int i = S + n_samples + lane; i < n_sort; i += 64) zall[i] = INFINITY;
-    __syncthreads();
-    for (int k = 2; k <= n_sort; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = lane; t < n_sort / 2; t += 64) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j clear
-                const int p = i | j;
-                const float a = zall[i], b = zall[p];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) {
-                    zall[i] = b;
-                    zall[p] = a;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (int i = lane; i < S + n_samples; i += 64) z_merged[ray * (int64_t)(S + n_samples) + i] = zall[i];
+    sample_pdf_ray(blockIdx.x, threadIdx.x, smem, bins_in, weights, w_ld, w_off, z_coarse, u_in, M, n_samples, n_sort,
+                   samples_out, z_merged, z_std);
 }
 
 hipError_t launch_sample_pdf(const float* bins, const float* weights, int w_ld, int w_off, const float* z_coarse,
@@ -346,6 +148,35 @@ __device__ __forceinline__ void cam_ray(const float* c2w, float fx, float fy, fl
     }
 }
 
+// what render() does to a ray (o, d) between get_rays and the chunk loop (nerf.ipynb:600-629): the unit viewing direction,
+// taken BEFORE the NDC warp, then ndc_rays (nerf_helpers.py:311-369, called with near = 1.0)
+__device__ __forceinline__ void unit_direction(const float (&d)[3], float (&v)[3]) {
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = __fdiv_rn(d[k], nrm);
+}
+__device__ __forceinline__ void ndc_warp(float ndc_cw, float ndc_ch, float (&o)[3], float (&d)[3]) {
+    const float near = 1.0f;                                                     // nerf.ipynb:619
+    const float tt = __fdiv_rn(-__fadd_rn(near, o[2]), d[2]);                    // nerf_helpers.py:342
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = __fadd_rn(o[k], __fmul_rn(tt, d[k]));
+    const float o0 = __fdiv_rn(__fmul_rn(ndc_cw, o[0]), o[2]);
+    const float o1 = __fdiv_rn(__fmul_rn(ndc_ch, o[1]), o[2]);
+    const float o2 = __fadd_rn(1.0f, __fdiv_rn(2.0f * near, o[2]));
+    const float d0 = __fmul_rn(ndc_cw, __fsub_rn(__fdiv_rn(d[0], d[2]), __fdiv_rn(o[0], o[2])));
+    const float d1 = __fmul_rn(ndc_ch, __fsub_rn(__fdiv_rn(d[1], d[2]), __fdiv_rn(o[1], o[2])));
+    const float d2 = __fdiv_rn(-2.0f * near, o[2]);
+    o[0] = o0; o[1] = o1; o[2] = o2;
+    d[0] = d0; d[1] = d1; d[2] = d2;
+}
+__device__ __forceinline__ void write_ray_record(float* r, const float (&o)[3], const float (&d)[3], const float (&v)[3],
+                                                 float near, float far, bool use_viewdirs) {
+    r[0] = o[0]; r[1] = o[1]; r[2] = o[2];
+    r[3] = d[0]; r[4] = d[1]; r[5] = d[2];
+    r[6] = near; r[7] = far;
+    if (use_viewdirs) { r[8] = v[0]; r[9] = v[1]; r[10] = v[2]; }
+}
+
 __global__ void raygen_kernel(const RayGenParams p, float* __restrict__ rays) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= p.n) return;
@@ -356,31 +187,35 @@ __global__ void raygen_kernel(const RayGenParams p, float* __restrict__ rays) {
     cam_ray(c.c2w, c.fx, c.fy, c.cx, c.cy, i, j, o, d);
     if (c.use_viewdirs) {
         // unit direction of the *viewing* camera, before NDC and before the static-camera override
-        const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
-#pragma unroll
-        for (int k = 0; k < 3; ++k) v[k] = __fdiv_rn(d[k], nrm);
+        unit_direction(d, v);
         if (c.has_static) cam_ray(c.c2w_static, c.fx, c.fy, c.cx, c.cy, i, j, o, d);
     }
-    if (c.ndc) {
-        const float near = 1.0f;                                                     // nerf.ipynb:619
-        const float tt = __fdiv_rn(-__fadd_rn(near, o[2]), d[2]);                    // nerf_helpers.py:342
-#pragma unroll
-        for (int k = 0; k < 3; ++k) o[k] = __fadd_rn(o[k], __fmul_rn(tt, d[k]));
-        const float o0 = __fdiv_rn(__fmul_rn(p.ndc_cw, o[0]), o[2]);
-        const float o1 = __fdiv_rn(__fmul_rn(p.ndc_ch, o[1]), o[2]);
-        const float o2 = __fadd_rn(1.0f, __fdiv_rn(2.0f * near, o[2]));
-        const float d0 = __fmul_rn(p.ndc_cw, __fsub_rn(__fdiv_rn(d[0], d[2]), __fdiv_rn(o[0], o[2])));
-        const float d1 = __fmul_rn(p.ndc_ch, __fsub_rn(__fdiv_rn(d[1], d[2]), __fdiv_rn(o[1], o[2])));
-        const float d2 = __fdiv_rn(-2.0f * near, o[2]);
-        o[0] = o0; o[1] = o1; o[2] = o2;
-        d[0] = d0; d[1] = d1; d[2] = d2;
-    }
-    const int ld = c.use_viewdirs ? 11 : 8;
-    float* r = rays + t * ld;
-    r[0] = o[0]; r[1] = o[1]; r[2] = o[2];
-    r[3] = d[0]; r[4] = d[1]; r[5] = d[2];
-    r[6] = c.near; r[7] = c.far;
-    if (c.use_viewdirs) { r[8] = v[0]; r[9] = v[1]; r[10] = v[2]; }
+    if (c.ndc) ndc_warp(p.ndc_cw, p.ndc_ch, o, d);
+    write_ray_record(rays + t * (c.use_viewdirs ? 11 : 8), o, d, v, c.near, c.far, c.use_viewdirs);
+}
+
+// render(rays=(rays_o, rays_d)) - the training loop's form (nerf.ipynb:1258) - packs a caller's batch the same way
+__global__ void pack_rays_kernel(const float* __restrict__ rays_o, int o_ld, const float* __restrict__ rays_d, int d_ld,
+                                 int64_t n, int ndc, float ndc_cw, float ndc_ch, float near, float far, int use_viewdirs,
+                                 float* __restrict__ rays) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float o[3] = {rays_o[t * o_ld], rays_o[t * o_ld + 1], rays_o[t * o_ld + 2]};
+    float d[3] = {rays_d[t * d_ld], rays_d[t * d_ld + 1], rays_d[t * d_ld + 2]};
+    float v[3] = {0.0f, 0.0f, 0.0f};
+    if (use_viewdirs) unit_direction(d, v);
+    if (ndc) ndc_warp(ndc_cw, ndc_ch, o, d);
+    write_ray_record(rays + t * (use_viewdirs ? 11 : 8), o, d, v, near, far, use_viewdirs != 0);
+}
+
+hipError_t launch_pack_rays(const nerf_camera& cam, const float* rays_o, int o_ld, const float* rays_d, int d_ld, int64_t n,
+                            float* rays, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const float cw = (float)(-1.0 / ((double)cam.W / (2.0 * cam.ndc_focal)));
+    const float ch = (float)(-1.0 / ((double)cam.H / (2.0 * cam.ndc_focal)));
+    hipLaunchKernelGGL(pack_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rays_o, o_ld, rays_d, d_ld, n,
+                       cam.ndc, cw, ch, cam.near, cam.far, cam.use_viewdirs, rays);
+    return hipGetLastError();
 }
 
 hipError_t launch_raygen(const nerf_camera& cam, int64_t first, int64_t n, float* rays, hipStream_t s) {

@@ -134,6 +134,12 @@ struct Pass {              // one network evaluated at P = N*S points with every
     unsigned* mask[kMaxDepth] = {};   // ReLU masks of the trunk layers, one bit per unit (MlpStore::mask), and the view layer's
     unsigned* mask_hv = nullptr;
     int vcat_ld = 0, C = 4;
+    // The kept activations and the gradients at the pre-activations BLOCKED by 32 points (MlpStore::blocked) instead of row-major:
+    // h[i], feat_blk (the feature vector; vcat then holds gamma(d) alone, voff = 0), dz[i], g_a (d feature), g_hv. Only when every
+    // producer and consumer is one of the fp16-pair kernels that know the layout (set_units).
+    bool blocked = false;
+    float* feat_blk = nullptr;
+    int voff = 0;            // column of gamma(d) in vcat
 };
 
 size_t pass_floats(const PackedNet& net, int64_t P) {
@@ -146,6 +152,7 @@ size_t pass_floats(const PackedNet& net, int64_t P) {
     f += (size_t)P * 2 * (net.out_ch > 8 ? net.out_ch : 0);
     f += (size_t)P * a.W * 2 + (size_t)P * (a.W / 2);
     f += (size_t)(a.D + 1) * ((size_t)P * 8 + 64);    // Pass::mask, mask_hv
+    f += (size_t)(2 * a.D + 6) * 32 * (size_t)(a.W + 64);      // blocked buffers are whole groups of 32 points; gamma(x) apart
     return f + 64 * 32;
 }
 
@@ -153,6 +160,7 @@ void carve_pass(Arena& ar, Pass& ps) {
     const PackedNet& net = *ps.net;
     const nerf_arch& a = net.arch;
     const int64_t P = ps.P;
+    const size_t Pg = (size_t)((P + 31) / 32 * 32);      // whole groups of 32 points (blocked buffers)
     ps.C = net.out_ch;
     float* E = ar.take((size_t)P * a.input_ch);
     ps.in.assign(a.D, nullptr);
@@ -163,7 +171,19 @@ void carve_pass(Arena& ar, Pass& ps) {
     ps.in_ld[0] = a.input_ch;
     for (int i = 0; i < a.D; ++i) {
         const bool next_cat = (i + 1 < a.D) && ((net.skip_in_mask >> (i + 1)) & 1);
-        if (next_cat) {
+        if (ps.blocked) {
+            // h_i in a buffer of its own, blocked by 32 points; a layer that reads cat[gamma(x), h_i] (nerf.py:79-80) finds gamma(x)
+            // in the narrow row-major buffer layer 0 reads (in[i + 1]: what the gamma(x) columns' weight gradients read)
+            ps.h[i] = ar.take(Pg * a.W);
+            ps.h_ld[i] = a.W;
+            if (next_cat) {      // (the same gamma(x) layer 0 reads: no second copy)
+                ps.in[i + 1] = E;
+                ps.in_ld[i + 1] = a.input_ch;
+            } else if (i + 1 < a.D) {
+                ps.in[i + 1] = ps.h[i];
+                ps.in_ld[i + 1] = a.W;
+            }
+        } else if (next_cat) {
             // [gamma(x) | h_i] (nerf.py:79-80), rows padded IN FRONT so that h_i starts on a 16-byte boundary and the row
             // stride is a multiple of four floats: the fused kernels then write and read h_i with 16-byte accesses (63
             // leading columns and a stride of 319 floats meant four dword stores for each of them)
@@ -183,19 +203,28 @@ void carve_pass(Arena& ar, Pass& ps) {
         }
     }
     if (a.use_viewdirs) {
-        ps.vcat_ld = (a.W + a.input_ch_views + 3) / 4 * 4;            // row stride a multiple of four floats, as above
-        ps.vcat = ar.take((size_t)P * ps.vcat_ld);                    // [feature | gamma(dir)] (nerf.py:93)
+        if (ps.blocked) {
+            ps.feat_blk = ar.take(Pg * a.W);                              // the feature vector, blocked
+            ps.vcat_ld = (a.input_ch_views + 3) / 4 * 4;                  // gamma(dir) alone (nerf.py:93 concatenates them)
+            ps.vcat = ar.take((size_t)P * ps.vcat_ld);
+            ps.voff = 0;
+        } else {
+            ps.vcat_ld = (a.W + a.input_ch_views + 3) / 4 * 4;            // row stride a multiple of four floats, as above
+            ps.vcat = ar.take((size_t)P * ps.vcat_ld);                    // [feature | gamma(dir)] (nerf.py:93)
+            ps.voff = a.W;
+        }
         ps.hv = ar.take((size_t)P * (a.W / 2));
     }
     ps.raw = ar.take((size_t)P * ps.C);
     ps.d_raw = ar.take((size_t)P * ps.C);
-    ps.g_a = ar.take((size_t)P * a.W);
+    const size_t rows = ps.blocked ? Pg : (size_t)P;
+    ps.g_a = ar.take(rows * a.W);
     ps.g_b = ar.take((size_t)P * a.W);
-    ps.g_hv = ar.take((size_t)P * (a.W / 2));
+    ps.g_hv = ar.take(rows * (a.W / 2));
     ps.dz.assign(a.D, nullptr);
     if (ps.fused_backward)
-        for (int i = 0; i < a.D; ++i) ps.dz[i] = ar.take((size_t)P * a.W);     // d(pre-activation) of every trunk layer
-    ps.maxes = (unsigned*)ar.take(kBwdMaxSlots);
+        for (int i = 0; i < a.D; ++i) ps.dz[i] = ar.take(rows * a.W);     // d(pre-activation) of every trunk layer
+    if (!ps.maxes) ps.maxes = (unsigned*)ar.take(kBwdMaxSlots);      // (the fused prologue zeroes one block holding both passes')
     if (ps.eq) {      // (the fp16-pair forward kernel always writes them)
         // ReLU masks, one bit per unit: [P][2 half-waves][4 words] per trunk layer, the view layer's in the same record size
         for (int i = 0; i < a.D; ++i) ps.mask[i] = (unsigned*)ar.take((size_t)P * 8);
@@ -240,6 +269,17 @@ bool pair_bwd_allowed() {
     return on;
 }
 
+// NERF_TRAIN_GLUE=legacy keeps the step's small stages as launches of their own (stratified depths, encodings, compositing,
+// resampling, losses, compositing backward: the stage kernels of ray_kernels.hip / train_kernels.hip) - the A/B switch of
+// the fused launches, which call the same device functions and are bit-identical (tests: test_train_glue_is_bit_identical)
+bool glue_legacy() {
+    static const bool on = [] {
+        const char* e = getenv("NERF_TRAIN_GLUE");
+        return e && (e[0] == 'l' || e[0] == 'L');
+    }();
+    return on;
+}
+
 bool gemm_forward_requested() {
     static const bool on = [] {
         const char* e = getenv("NERF_TRAIN_GEMM_FORWARD");
@@ -250,27 +290,42 @@ bool gemm_forward_requested() {
 
 // gamma(x) into layer 0's input and into every concat buffer, gamma(dir) into the view concat buffer: one launch for the
 // usual single skip connection (the kernel writes a second destination), one more per further skip layer
-hipError_t embed_inputs(Pass& ps, const float* rays, int ray_ld, const float* z, int Lx, int Lv, hipStream_t s) {
+// The training step's first launch (train_kernels.hip, embed_train_kernel<true>): the coarse pass's depths are made where its
+// encodings are, and the step's small accumulators zeroed by the same launch
+struct Prologue {
+    int lindisp;
+    const float* t_rand;
+    unsigned* zero;
+    int n_zero;
+};
+
+hipError_t embed_inputs(Pass& ps, const float* rays, int ray_ld, float* z, int Lx, int Lv, hipStream_t s,
+                        const Prologue* pro = nullptr) {
     const PackedNet& net = *ps.net;
     const nerf_arch& a = net.arch;
     int first = -1;
     for (int i = 1; i < a.D && first < 0; ++i)
         if ((net.skip_in_mask >> i) & 1) first = i;
-    hipError_t e = launch_embed_train(rays, ray_ld, z, ps.P, ps.S, Lx, Lv, ps.in[0], ps.in_ld[0],
-                                      first > 0 ? ps.in[first] : nullptr, first > 0 ? ps.in_ld[first] : 0, ps.vcat,
-                                      ps.vcat_ld, a.W, s);
+    if (ps.blocked) first = -1;      // (blocked passes: the skip layers' gamma(x) IS layer 0's buffer, carve_pass)
+    hipError_t e = pro ? launch_train_prologue(rays, ray_ld, ps.N, ps.S, pro->lindisp, pro->t_rand, z, Lx, Lv, ps.in[0],
+                                               ps.in_ld[0], first > 0 ? ps.in[first] : nullptr,
+                                               first > 0 ? ps.in_ld[first] : 0, ps.vcat, ps.vcat_ld, ps.voff, pro->zero,
+                                               pro->n_zero, s)
+                       : launch_embed_train(rays, ray_ld, z, ps.P, ps.S, Lx, Lv, ps.in[0], ps.in_ld[0],
+                                            first > 0 ? ps.in[first] : nullptr, first > 0 ? ps.in_ld[first] : 0, ps.vcat,
+                                            ps.vcat_ld, ps.voff, s);
     for (int i = first + 1; first > 0 && i < a.D && e == hipSuccess; ++i)
         if ((net.skip_in_mask >> i) & 1)
             e = launch_embed_train(rays, ray_ld, z, ps.P, ps.S, Lx, 0, ps.in[i], ps.in_ld[i], nullptr, 0, nullptr, 0, 0, s);
     return e;
 }
 
-int forward_pass_fused(Pass& ps, const float* rays, int ray_ld, const float* z, hipStream_t s) {
+int forward_pass_fused(Pass& ps, const float* rays, int ray_ld, float* z, hipStream_t s, const Prologue* pro) {
     const PackedNet& net = *ps.net;
     const nerf_arch& a = net.arch;
     const int Lx = (a.input_ch - 3) / 6, Lv = a.use_viewdirs ? (a.input_ch_views - 3) / 6 : 0;
     // the encodings are still written out: they are the X of dW = dY^T X for layer 0, the skip layer and the view layer
-    HIP_TRY(embed_inputs(ps, rays, ray_ld, z, Lx, Lv, s));
+    HIP_TRY(embed_inputs(ps, rays, ray_ld, z, Lx, Lv, s, pro));
     MlpLaunch m{};
     m.stream = net.d_stream;
     m.bias = net.d_bias;
@@ -294,11 +349,12 @@ int forward_pass_fused(Pass& ps, const float* rays, int ray_ld, const float* z, 
         m.st.h_ld[i] = ps.h_ld[i];
     }
     if (a.use_viewdirs) {
-        m.st.feat = ps.vcat;
-        m.st.feat_ld = ps.vcat_ld;
+        m.st.feat = ps.blocked ? ps.feat_blk : ps.vcat;
+        m.st.feat_ld = ps.blocked ? a.W : ps.vcat_ld;
         m.st.hv = ps.hv;
         m.st.hv_ld = a.W / 2;
     }
+    m.st.blocked = ps.blocked ? 1 : 0;
     PackedNet& w = const_cast<PackedNet&>(net);      // (the lazily refreshed streams are caches of the parameters)
     if (ps.eq) {
         // the fp16-pair kernel on the row-equalised network - the stream the renderer uses: what it keeps (activations, ReLU
@@ -328,17 +384,17 @@ int forward_pass_fused(Pass& ps, const float* rays, int ray_ld, const float* z, 
     return NERF_OK;
 }
 
-int forward_pass(Pass& ps, const float* rays, int ray_ld, const float* z, hipStream_t s) {
+int forward_pass(Pass& ps, const float* rays, int ray_ld, float* z, hipStream_t s, const Prologue* pro = nullptr) {
     const PackedNet& net = *ps.net;
     const nerf_arch& a = net.arch;
     // (the fused kernels keep 256-wide rows: a narrower network, which they evaluate zero-padded, trains on the chain below)
     if (!gemm_forward_requested() && ps.C == net.out_ch && a.D <= kMaxDepth && a.W == kWidth)
-        return forward_pass_fused(ps, rays, ray_ld, z, s);
+        return forward_pass_fused(ps, rays, ray_ld, z, s, pro);
     const float* wt = net.train.d_wt;
     const float* prm = net.d_params;
     const int Lx = (a.input_ch - 3) / 6, Lv = a.use_viewdirs ? (a.input_ch_views - 3) / 6 : 0;
     // gamma(x) into layer 0's input and into every concat buffer; gamma(dir) into the view concat buffer
-    HIP_TRY(embed_inputs(ps, rays, ray_ld, z, Lx, Lv, s));
+    HIP_TRY(embed_inputs(ps, rays, ray_ld, z, Lx, Lv, s, pro));
     for (int i = 0; i < a.D; ++i) {
         const LinearDesc& d = net.linears[i];
         GemmRows g{ps.in[i], ps.in_ld[i], wt + d.w_off, d.out, ps.h[i], ps.h_ld[i], ps.P, d.out, d.in,
@@ -469,6 +525,7 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     b.out.hv_ld = views.out;
     b.out.feat = d_feat;
     b.out.feat_ld = a.W;
+    b.out.blocked = ps.blocked ? 1 : 0;
     // (ps.maxes was zeroed before the forward pass, which - on the fp16-pair kernel - has entered the kept activations'
     // maxima and the feature vector's; the backward kernels add the gradients', the fp32 one the kept ones as well)
     const bool pair_dw = ps.precision == NERF_PRECISION_F16X2 && pair_dw_allowed() && ps.maxes != nullptr;
@@ -503,6 +560,10 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     }();
     const bool alpha_rides = rider_wanted && batched && pair_dw && grad_pair_takes_riders() && a.D + 2 <= kMaxGradJobs &&
                              hl_ld % 4 == 0;
+    if (ps.blocked && !(alpha_rides && batched && pair_dw && feat_known)) {
+        set_error("internal: the blocked activation layout was chosen for a pass whose weight gradients cannot read it");
+        return NERF_E_INVALID;
+    }
     if (!alpha_rides && (rc = grad_linear(net, alpha, ps.d_raw + 3, ps.C, hl, hl_ld, ps.P, sc, s, eq))) return rc;
     if (!batched) {
         if ((rc = grad_linear(net, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, ps.P, sc, s, eq))) return rc;
@@ -518,13 +579,35 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     // (pairs: the jobs whose operands the backward kernel has measured - d z_i / d feature against the kept h_{i-1}, the
     // view layer's against a bound of the feature vector - go to the fp16-pair kernel when the context's arithmetic is F16X2)
     GradBatch wide{}, narrow{}, pairs{};
+    // blocked: 0, or bit 0 = dY blocked by 32 points, bit 1 = X blocked with its feature 0 at column b_first (GradJob)
     auto job = [&](GradBatch& b, const LinearDesc& d, const float* dY, int ldy, const float* X, int ldx, int n0, int n1,
-                   bool with_db, const unsigned* a_max = nullptr, const unsigned* b_max = nullptr) {
-        b.job[b.n++] = GradJob{dY, ldy, X, ldx, d.out, n0, n1, grad + d.w_off, d.in, with_db ? grad + d.b_off : nullptr,
-                               nullptr, nullptr, a_max, b_max, grad_exps(net, (int)(&d - &net.linears[0]), eq)};
+                   bool with_db, const unsigned* a_max = nullptr, const unsigned* b_max = nullptr, int blocked = 0,
+                   int b_first = 0) {
+        GradJob& j = b.job[b.n++];
+        j = GradJob{dY, ldy, X, ldx, d.out, n0, n1, grad + d.w_off, d.in, with_db ? grad + d.b_off : nullptr,
+                    nullptr, nullptr, a_max, b_max, grad_exps(net, (int)(&d - &net.linears[0]), eq)};
+        j.blocked = blocked;
+        j.b_first = b_first;
     };
     GradBatch& hidden = pair_dw ? pairs : wide;
     auto mx = [&](int slot) -> const unsigned* { return pair_dw ? ps.maxes + slot : nullptr; };
+    if (ps.blocked) {
+        // every hidden-width operand blocked by 32 points, in a buffer of its own; the gamma(x) / gamma(d) columns' jobs read
+        // a blocked dY against a narrow row-major X whose column 0 is column `first` of the Linear's input
+        job(pairs, feat, d_feat, a.W, ps.h[a.D - 1], a.W, 0, a.W, true, mx(kBwdMaxFeat), mx(kBwdMaxKept + a.D - 1), 3, 0);
+        job(pairs, views, ps.g_hv, views.out, ps.feat_blk, a.W, 0, a.W, true, mx(kBwdMaxViews), mx(kBwdMaxFeatValue), 3, 0);
+        if (views.in > a.W) job(narrow, views, ps.g_hv, views.out, ps.vcat - a.W, ps.vcat_ld, a.W, views.in, false, nullptr, nullptr, 1);
+        for (int i = a.D - 1; i >= 0; --i) {
+            const LinearDesc& d = net.linears[i];
+            if (d.in >= a.W) {
+                const int lead = d.in - a.W;                                           // cat[gamma(x), h] (nerf.py:79-80)
+                job(pairs, d, ps.dz[i], a.W, ps.h[i - 1], a.W, lead, d.in, true, mx(i), mx(kBwdMaxKept + i - 1), 3, lead);
+                if (lead > 0) job(narrow, d, ps.dz[i], a.W, ps.in[i], ps.in_ld[i], 0, lead, false, nullptr, nullptr, 1);
+            } else {
+                job(narrow, d, ps.dz[i], a.W, ps.in[i], ps.in_ld[i], 0, d.in, true, nullptr, nullptr, 1);   // layer 0: gamma(x) only
+            }
+        }
+    } else {
     job(hidden, feat, d_feat, a.W, hl, hl_ld, 0, a.W, true, mx(kBwdMaxFeat), mx(kBwdMaxKept + a.D - 1));
     job(feat_known ? pairs : wide, views, ps.g_hv, views.out, ps.vcat, ps.vcat_ld, 0, a.W, true, mx(kBwdMaxViews),
         mx(kBwdMaxFeatValue));                                                        // cat[feature, gamma(d)] (nerf.py:93)
@@ -538,6 +621,7 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
         } else {
             job(narrow, d, ps.dz[i], a.W, ps.in[i], ps.in_ld[i], 0, d.in, true);       // layer 0: gamma(x) only
         }
+    }
     }
     for (GradBatch* b : {&pairs, &wide, &narrow}) {
         if (b->n == 0) continue;
@@ -711,6 +795,20 @@ void set_units(Pass& ps) {
     ps.eq = ps.precision == NERF_PRECISION_F16X2 && pair_forward_allowed() && fused_forward && a.use_viewdirs &&
             (uint64_t)ps.P * (uint64_t)(a.W + a.input_ch + 4) * 4u < ((uint64_t)1 << 32);
     ps.pair_backward = ps.eq && ps.fused_backward && pair_bwd_allowed();
+    // Blocked by 32 points (MlpStore::blocked; NERF_TRAIN_BLOCKED=0: row-major, the A/B switch): when the three fp16-pair
+    // kernels run the pass and the weight gradients go through the batched launches that read the layout - the conditions
+    // backward_pass_fused puts on `batched`, `pair_dw`, `feat_known` and the alpha rider
+    static const bool blocked_wanted = [] {
+        const char* e = getenv("NERF_TRAIN_BLOCKED");
+        return !(e && *e == '0');
+    }();
+    static const bool rider_on = [] {
+        const char* e = getenv("NERF_TRAIN_DW_RIDER");
+        return !(e && *e == '0');
+    }();
+    ps.blocked = blocked_wanted && ps.pair_backward && pair_dw_allowed() && rider_on && grad_pair_takes_riders() &&
+                 gemm_tn_is_direct(a.W) && gemm_tn_is_direct(a.W / 2) && a.input_ch <= 64 && a.input_ch_views <= 64 &&
+                 a.D + 2 <= kMaxGradJobs && ps.net->out_ch == 4 && (uint64_t)ps.P * 1024u < ((uint64_t)1 << 32);
 }
 
 }  // namespace
@@ -786,7 +884,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     const int64_t Pc = N * Sc, Pf = Si ? N * Sf : 0;
     const int n_slices = 256;
     const size_t part_floats = (size_t)n_slices * 256 * (size_t)(nc.arch.W + nc.arch.input_ch + 64);
-    const size_t small = (size_t)N * (Sc * 2 + (Si ? Si + Sf * 2 : 0) + 16) + 4096;
+    const size_t small = (size_t)N * (Sc * 2 + (Si ? Si + Sf * 2 : 0) + 24) + 8192;
     rc = ensure_workspace(c, arena_bytes({small, pass_floats(nc, Pc), Si ? pass_floats(nf, Pf) : 1, part_floats,
                                           (size_t)n_slices * 512}) +
                                  (1 << 20));
@@ -805,6 +903,10 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     float* loss_dev = ar.take(4);
     TnScratch sc{ar.take(part_floats), ar.take((size_t)n_slices * 512), n_slices, 0, 0, part_floats, (size_t)n_slices * 512};
 
+    const bool fused_glue = !glue_legacy();
+    // one block of words that the prologue zeroes: both passes' running maxima and the loss kernel's ticket
+    unsigned* zero_block = (unsigned*)ar.take(2 * kBwdMaxSlots + 32);
+    double* loss_part = (double*)ar.take((size_t)4 * N + 16);      // [2][N] per-ray sums of squares
     Pass pc;
     pc.net = &nc;
     pc.N = N;
@@ -814,6 +916,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     pc.precision = precision;
     pc.ctx = c;
     pc.loose = c->d_loose + kLooseTrain;
+    pc.maxes = zero_block;
     set_units(pc);
     carve_pass(ar, pc);
     Pass pf;
@@ -826,10 +929,55 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
         pf.precision = precision;
         pf.ctx = c;
         pf.loose = c->d_loose + kLooseTrain;
+        pf.maxes = zero_block + kBwdMaxSlots;
         set_units(pf);
         carve_pass(ar, pf);
     }
+    unsigned* ticket = zero_block + 2 * kBwdMaxSlots;
+    float* rgb_last = Si ? rgb_f : rgb_c;
 
+    if (fused_glue) {
+        // ---- forward (render(..., retraw=True, **render_kwargs_train), nerf.ipynb:1258), the small stages fused ----
+        const Prologue pro{r->lindisp, r->perturb ? r->t_rand : nullptr, zero_block, 2 * kBwdMaxSlots + 32};
+        if ((rc = forward_pass(pc, r->rays, r->ray_stride, z_c, s, &pro))) return rc;
+        if (Si) {
+            HIP_TRY(launch_train_mid(pc.raw, pc.C, z_c, r->rays + 3, r->ray_stride, r->noise0, r->white_bkgd, N, Sc, rgb_c, w_c,
+                                     r->perturb ? r->u_rand : nullptr, Si, z_f, s));      // z_samples are detached (nerf.ipynb:464)
+            if ((rc = forward_pass(pf, r->rays, r->ray_stride, z_f, s))) return rc;
+        }
+        // ---- raw2outputs of the last pass, loss = img2mse(rgb, target) [+ img2mse(rgb0, target)] (nerf.ipynb:1262-1272),
+        //      and the backward of both raw2outputs: one launch ----
+        Pass& pl = Si ? pf : pc;
+        TrainEpilogue e{};
+        e.rays_d = r->rays + 3;
+        e.d_ld = r->ray_stride;
+        e.target = r->target;
+        e.N = N;
+        e.white_bkgd = r->white_bkgd;
+        e.raw_l = pl.raw; e.C_l = pl.C; e.z_l = Si ? z_f : z_c; e.noise_l = Si ? r->noise : r->noise0; e.S_l = Si ? Sf : Sc;
+        e.d_raw_l = pl.d_raw;
+        if (Si) {
+            e.raw_c = pc.raw; e.C_c = pc.C; e.z_c = z_c; e.noise_c = r->noise0; e.S_c = Sc; e.d_raw_c = pc.d_raw; e.rgb_c = rgb_c;
+        }
+        e.out_rgb = r->rgb_map ? r->rgb_map : rgb_last;
+        e.out_rgb0 = Si ? r->rgb0 : nullptr;
+        e.part = loss_part;
+        e.ticket = ticket;
+        e.loss_dev = loss_dev;
+        e.out_loss = r->loss;
+        e.out_stats = r->stats;
+        HIP_TRY(launch_train_epilogue(e, s));
+        // ---- backward ----
+        sc.P = Pc;
+        if ((rc = backward_pass(pc, sc, s))) return rc;
+        nc.train.grads_valid = true;
+        if (Si) {
+            sc.P = Pf;
+            sc.accumulate = shared ? 1 : 0;
+            if ((rc = backward_pass(pf, sc, s))) return rc;
+            nf.train.grads_valid = true;
+        }
+    } else {
     // ---- forward (render(..., retraw=True, **render_kwargs_train), nerf.ipynb:1258) ----
     for (Pass* p : {&pc, &pf})
         if (p->maxes) HIP_TRY(hipMemsetAsync(p->maxes, 0, kBwdMaxSlots * sizeof(unsigned), s));
@@ -845,12 +993,12 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
                                  nullptr, nullptr, w_f, nullptr, s));
     }
     // ---- loss = img2mse(rgb, target) [+ img2mse(rgb0, target)] and its gradients (nerf.ipynb:1262-1272) ----
-    float* rgb_last = Si ? rgb_f : rgb_c;
     HIP_TRY(launch_mse(rgb_last, r->target, N * 3, Si ? g_f : g_c, red, loss_dev, s));
     if (Si) HIP_TRY(launch_mse(rgb_c, r->target, N * 3, g_c, red + 512, loss_dev + 1, s));
     if (r->loss) {
         HIP_TRY(hipMemcpyAsync(r->loss, loss_dev, sizeof(float) * (Si ? 2 : 1), hipMemcpyDeviceToDevice, s));
     }
+    if (r->stats) HIP_TRY(launch_train_stats(loss_dev, Si > 0, r->stats, s));
     if (r->rgb_map) HIP_TRY(hipMemcpyAsync(r->rgb_map, rgb_last, (size_t)N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (r->rgb0 && Si) HIP_TRY(hipMemcpyAsync(r->rgb0, rgb_c, (size_t)N * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
 
@@ -867,6 +1015,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
         sc.accumulate = shared ? 1 : 0;
         if ((rc = backward_pass(pf, sc, s))) return rc;
         nf.train.grads_valid = true;
+    }
     }
     // ---- optimizer.step() (torch.optim.Adam, nerf.ipynb:905, :1275) ----
     if (r->apply_update) {

@@ -78,9 +78,17 @@ void grad_batch_kernel(const GradBatch b) {
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
     float asum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
-    const float* pa = g.A + (p_begin + k) * g.lda + m_base + 4 * i;
+    // A (dY) row-major, or blocked by 32 points (GradJob::blocked bit 0: what the fp16-pair backward-data kernel writes): this
+    // lane's 16 bytes of point p - features m_base + 4 i .. + 3 - then sit in piece (m_base + 4 i) / 8 of p's group
+    const bool a_blk = (g.blocked & 1) != 0;
+    const int64_t a_group = 32 * (int64_t)g.Mo;
+    const int a_lane = ((m_base + 4 * i) >> 3) * 256 + (i & 1) * 4 + k * 8;
+    auto a_at = [&](int64_t p) -> const float* {      // p: the k-step's first point (even); this lane's point is p + k
+        return a_blk ? g.A + (p >> 5) * a_group + (int)(p & 31) * 8 + a_lane : g.A + (p + k) * g.lda + m_base + 4 * i;
+    };
+    int64_t pp = p_begin;                               // point of the next k-step to be loaded
     const float* pb = g.B + (p_begin + k) * g.ldb + col;
-    const int64_t sa = 2 * (int64_t)g.lda, sb = 2 * (int64_t)g.ldb;
+    const int64_t sb = 2 * (int64_t)g.ldb;
 
     auto step = [&](const f32x4u& a, const TnCols<NT>& b) {
 #pragma unroll
@@ -100,9 +108,9 @@ void grad_batch_kernel(const GradBatch b) {
     if (n_steps >= kDepth) {
 #pragma unroll
         for (int j = 0; j < kDepth; ++j) {
-            ra[j] = *(const f32x4u*)pa;
+            ra[j] = *(const f32x4u*)a_at(pp);
             rb[j] = tn_load_cols<NT>(pb);
-            pa += sa;
+            pp += 2;
             pb += sb;
         }
         for (; s + 2 * kDepth <= n_steps; s += kDepth) {
@@ -113,9 +121,9 @@ void grad_batch_kernel(const GradBatch b) {
                 // of all eight k-steps in front of the group's 128 MFMAs, ~110 instructions with an empty matrix pipe.
                 step(ra[j], rb[j]);
                 __builtin_amdgcn_sched_barrier(0);
-                ra[j] = *(const f32x4u*)pa;      // k-step s + kDepth + j, into the registers just consumed
+                ra[j] = *(const f32x4u*)a_at(pp);      // k-step s + kDepth + j, into the registers just consumed
                 rb[j] = tn_load_cols<NT>(pb);
-                pa += sa;
+                pp += 2;
                 pb += sb;
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -131,7 +139,7 @@ void grad_batch_kernel(const GradBatch b) {
 #pragma unroll
         for (int tn = 0; tn < NT; ++tn) b.v[tn] = 0.0f;
         if (p + k < p_end) {
-            a = *(const f32x4u*)(g.A + (p + k) * g.lda + m_base + 4 * i);
+            a = *(const f32x4u*)a_at(p);
             b = tn_load_cols<NT>(g.B + (p + k) * g.ldb + col);
         }
         step(a, b);
@@ -326,24 +334,37 @@ void grad_batch_pair_kernel(const GradBatch b) {
 // wave, 128 KiB per CU, twice what two register sets held. Loads return in order, so "step s has landed" is
 // vmcnt(16 x the steps issued after it).
 // ---------------------------------------------------------------------------------------------
+// BLK (GradJob::blocked = 3): both operands are blocked by 32 points (MlpStore::blocked), i.e. cut into KiB pieces of [32
+// points][8 features]. A 16-point step then wants HALF of sixteen pieces per operand, and a load instruction fetches two such
+// halves - lanes 0-31 the 512 bytes of piece j, lanes 32-63 those of piece j + 8 - which is as coalesced as the two rows of a
+// row-major load. The pieces land verbatim ([16 points][2 half-waves][4 features] each), and the lane that computes with
+// features 4 i .. 4 i + 3 reads its eight points back from piece i / 2 at a stride of 32 bytes. So that the 16 lanes a
+// ds_read_b128 serves per cycle ({0-3, 12-15, 20-27}, ... : MI355X_MICROARCH.md, LDS) meet 16 different 16-byte bank slots,
+// image j starts at j x (1024 + 32): the eight pieces j of a group then differ by 32 bytes modulo the 256-byte bank row, the
+// two half-waves h by 16 (SQ_LDS_BANK_CONFLICT stays 0). Same loads per step, same bytes in flight, same registers after the
+// read-back as the row-major form - only the addresses differ.
 constexpr int kDmaSlots = 2;
-constexpr int kDmaRiderOff = 16 * 1024;        // behind a step's sixteen KiB: its sixteen y values (GradJob::y), one 256-byte load
-constexpr int kDmaSlotBytes = 16 * 1024 + 256;
+constexpr int kDmaImage = 1024 + 32;           // one load instruction's KiB in LDS (BLK: padded, see above)
+constexpr int kDmaRiderOff = 16 * kDmaImage;   // behind a step's sixteen images: its sixteen y values (GradJob::y), one 256-byte load
+constexpr int kDmaSlotBytes = 16 * kDmaImage + 256;
 constexpr size_t kPairDmaLds = (size_t)4 * kDmaSlots * kDmaSlotBytes;
 
 template <int OFF>
 __device__ __forceinline__ void dma_read(f32x4u& q, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(q) : "v"(addr), "n"(OFF) : "memory");
 }
-template <int J>
+// point J of this lane's eight: row-major images hold one point (two, for the two half-waves) each, blocked ones eight features
+// of sixteen points each (`addr` then points at this lane's piece, half-wave and point octet)
+template <int J, bool BLK>
 __device__ __forceinline__ void dma_read_set(PairSet& r, unsigned addr) {
     if constexpr (J < 8) {
-        dma_read<J * 1024>(r.a[J], addr);
-        dma_read<8192 + J * 1024>(r.b[J], addr);
-        dma_read_set<J + 1>(r, addr);
+        dma_read<BLK ? J * 32 : J * kDmaImage>(r.a[J], addr);
+        dma_read<8 * kDmaImage + (BLK ? J * 32 : J * kDmaImage)>(r.b[J], addr);
+        dma_read_set<J + 1, BLK>(r, addr);
     }
 }
 
+template <bool BLK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void grad_batch_pair_dma_kernel(const GradBatch b) {
     extern __shared__ __attribute__((aligned(16))) char dma_ring[];
@@ -380,29 +401,47 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
     const float* py = has_y ? g.y + (p_begin + (lane & 15)) * g.ldy : nullptr;
     const int64_t step_y = 16 * (int64_t)g.ldy;
 
-    const float* pa = g.A + (p_begin + 8 * kh) * g.lda + m_base + 4 * i;
-    const float* pb = g.B + (p_begin + 8 * kh) * g.ldb + col;
+    // row-major: load j of a step = points j (lanes 0-31) and 8 + j (lanes 32-63), features m_base + 4 i .. + 3.
+    // BLK: load j = piece j (lanes 0-31) and piece 8 + j (lanes 32-63) of the wave's sixteen, the 16-point half the step is in;
+    //      lane l < 32 fetches bytes 16 l .. of that half: (point l / 2, half-wave l % 2).
+    const int b_feat0 = c_base - (BLK ? g.b_first : 0);      // BLK: B's feature index of this wave's first column
+    const float* pa = BLK ? g.A + (p_begin >> 5) * (32 * (int64_t)g.Mo) + ((p_begin >> 4) & 1) * 128 + ((m_base >> 3) + 8 * kh) * 256 + 4 * i
+                          : g.A + (p_begin + 8 * kh) * g.lda + m_base + 4 * i;
+    const float* pb = BLK ? g.B + (p_begin >> 5) * (32 * (int64_t)256) + ((p_begin >> 4) & 1) * 128 + ((b_feat0 >> 3) + 8 * kh) * 256 + 4 * i
+                          : g.B + (p_begin + 8 * kh) * g.ldb + col;
     const int64_t step_a = 16 * (int64_t)g.lda, step_b = 16 * (int64_t)g.ldb;
+    const int64_t load_a = BLK ? 256 : (int64_t)g.lda, load_b = BLK ? 256 : (int64_t)g.ldb;      // from load j to load j + 1
+    // BLK: a step moves on to the other half of the group (+ 128 floats) or to the first half of the next one
+    const int64_t group_a = 32 * (int64_t)g.Mo - 128, group_b = 32 * (int64_t)256 - 128;
+    int half = (int)((p_begin >> 4) & 1);
     char* my = dma_ring + (size_t)wave * kDmaSlots * kDmaSlotBytes;
     const unsigned my_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)my;
-    const unsigned my_addr = my_lds + lane * 16;
+    // where this lane reads back from: lane x 16 of every image, or (BLK) piece i / 2 = image (i / 2) % 8, its upper 512 bytes for
+    // pieces 8..15, this lane's point octet (8 kh) and half-wave (i % 2)
+    const unsigned my_addr = BLK ? my_lds + ((i >> 1) & 7) * kDmaImage + (i >> 4) * 512 + kh * 256 + (i & 1) * 16 : my_lds + lane * 16;
 
     auto issue = [&](int slot) {      // the sixteen loads of the step at (pa, pb) into `slot`
         char* base = my + slot * kDmaSlotBytes;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + j * (int64_t)g.lda),
-                                             (__attribute__((address_space(3))) void*)(base + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + j * (int64_t)g.ldb),
-                                             (__attribute__((address_space(3))) void*)(base + 8192 + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + j * load_a),
+                                             (__attribute__((address_space(3))) void*)(base + j * kDmaImage), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + j * load_b),
+                                             (__attribute__((address_space(3))) void*)(base + 8 * kDmaImage + j * kDmaImage), 16, 0, 0);
         }
         if (has_y) {      // lane l fetches y of point (l & 15) of the step: LDS [16 floats] x 4 copies
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)py,
                                              (__attribute__((address_space(3))) void*)(base + kDmaRiderOff), 4, 0, 0);
             py += step_y;
         }
-        pa += step_a;
-        pb += step_b;
+        if constexpr (BLK) {
+            pa += half ? group_a : 128;
+            pb += half ? group_b : 128;
+            half ^= 1;
+        } else {
+            pa += step_a;
+            pb += step_b;
+        }
     };
     auto ride = [&](const PairSet& r, const f32x4u& y0, const f32x4u& y1) {      // y of this lane's eight points
         typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -454,7 +493,7 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         PairSet r;
         f32x4u y0 = {0.0f, 0.0f, 0.0f, 0.0f}, y1 = y0;
-        dma_read_set<0>(r, my_addr + slot * kDmaSlotBytes);
+        dma_read_set<0, BLK>(r, my_addr + slot * kDmaSlotBytes);
         if (has_y) {
             const unsigned ya = my_lds + slot * kDmaSlotBytes + kh * 32;
             dma_read<kDmaRiderOff>(y0, ya);
@@ -479,8 +518,13 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
             r.a[j] = z;
             r.b[j] = z;
             if (p < p_end) {
-                r.a[j] = *(const f32x4u*)(g.A + p * g.lda + m_base + 4 * i);
-                r.b[j] = *(const f32x4u*)(g.B + p * g.ldb + col);
+                if constexpr (BLK) {      // piece (feature / 8) of p's group, 32 bytes per point, 16 per half-wave
+                    r.a[j] = *(const f32x4u*)(g.A + (p >> 5) * (32 * (int64_t)g.Mo) + ((m_base + 4 * i) >> 3) * 256 + (int)(p & 31) * 8 + (i & 1) * 4);
+                    r.b[j] = *(const f32x4u*)(g.B + (p >> 5) * (32 * (int64_t)256) + ((b_feat0 + 4 * i) >> 3) * 256 + (int)(p & 31) * 8 + (i & 1) * 4);
+                } else {
+                    r.a[j] = *(const f32x4u*)(g.A + p * g.lda + m_base + 4 * i);
+                    r.b[j] = *(const f32x4u*)(g.B + p * g.ldb + col);
+                }
             }
         }
         if (has_y) {
@@ -641,14 +685,25 @@ static hipError_t launch_grad_batch_impl(GradBatch& b, bool wide, float* part, s
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64 && !raised[dev]) {
-            e = hipFuncSetAttribute((const void*)grad_batch_pair_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPairDmaLds);
+            e = hipFuncSetAttribute((const void*)grad_batch_pair_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPairDmaLds);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)grad_batch_pair_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPairDmaLds);
             if (e != hipSuccess) return e;
             raised[dev] = true;
         }
-        hipLaunchKernelGGL(grad_batch_pair_dma_kernel, grid, dim3(256), kPairDmaLds, s, b);
-    } else if (pair) hipLaunchKernelGGL(grad_batch_pair_kernel, grid, dim3(256), 0, s, b);
-    else if (wide) hipLaunchKernelGGL(grad_batch_kernel<4>, grid, dim3(256), 0, s, b);
-    else hipLaunchKernelGGL(grad_batch_kernel<1>, grid, dim3(256), 0, s, b);
+        // a batch is blocked by 32 points as a whole (every job's A and B) or not at all
+        int n_blk = 0;
+        for (int j = 0; j < b.n; ++j) n_blk += b.job[j].blocked == 3 ? 1 : 0;
+        if (n_blk != 0 && n_blk != b.n) return hipErrorInvalidValue;
+        if (n_blk) hipLaunchKernelGGL(grad_batch_pair_dma_kernel<true>, grid, dim3(256), kPairDmaLds, s, b);
+        else hipLaunchKernelGGL(grad_batch_pair_dma_kernel<false>, grid, dim3(256), kPairDmaLds, s, b);
+    } else {
+        for (int j = 0; j < b.n; ++j)      // (only the LDS-prefetch kernel reads blocked X; the fp32 kernels read blocked dY)
+            if ((b.job[j].blocked & 2) || (pair && b.job[j].blocked)) return hipErrorInvalidValue;
+        if (pair) hipLaunchKernelGGL(grad_batch_pair_kernel, grid, dim3(256), 0, s, b);
+        else if (wide) hipLaunchKernelGGL(grad_batch_kernel<4>, grid, dim3(256), 0, s, b);
+        else hipLaunchKernelGGL(grad_batch_kernel<1>, grid, dim3(256), 0, s, b);
+    }
     hipLaunchKernelGGL(grad_batch_reduce_kernel, dim3((unsigned)((max_threads + 255) / 256), (unsigned)n_all), dim3(256), 0, s, b);
     return hipGetLastError();
 }

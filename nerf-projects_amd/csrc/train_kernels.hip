@@ -15,6 +15,7 @@
 #include <math.h>
 
 #include "nerf_internal.h"
+#include "ray_device.h"
 
 namespace nerf {
 
@@ -636,21 +637,50 @@ hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, flo
 // every destination was a launch of its own that evaluated the encoding again).
 // ---------------------------------------------------------------------------------------------
 constexpr int kEmbedPoints = 64;
-__global__ __launch_bounds__(256) void embed_train_kernel(const float* __restrict__ rays, int ray_ld, const float* __restrict__ z,
+// PROLOGUE (the training step's first launch): the depths are not read but MADE here - render_rays' stratified sampling
+// (stratified_z, the expression of stratified_kernel) - and written to `z` for the kernels that follow, and workgroup 0
+// zeroes the step's small accumulators (`zero`, n_zero words: the passes' running maxima, the loss kernel's ticket): one
+// launch where there were four.
+struct EmbedPrologue {
+    const float* t_rand;     // [N, S] jitter, or nullptr
+    int lindisp;
+    unsigned* zero;
+    int n_zero;
+};
+template <bool PROLOGUE>
+__global__ __launch_bounds__(256) void embed_train_kernel(const float* __restrict__ rays, int ray_ld, float* __restrict__ z,
                                                           int64_t P, int S, int Lx, int Lv, float* __restrict__ x0, int ld0,
                                                           float* __restrict__ x1, int ld1, float* __restrict__ vcat, int ldv,
-                                                          int voff) {
+                                                          int voff, const EmbedPrologue pro) {
     __shared__ float sx[kEmbedPoints][64];   // 3 + 6 Lx <= 63 columns
     __shared__ float sv[kEmbedPoints][28];   // 3 + 6 Lv <= 27 columns
+    __shared__ float sz[kEmbedPoints];
     const int64_t p0 = (int64_t)blockIdx.x * kEmbedPoints;
     const int n_here = (int)((P - p0) < kEmbedPoints ? (P - p0) : kEmbedPoints);
     const int fx = Lx + 1, fv = Lv + 1;      // frequency slot 0 is the identity term
+    if constexpr (PROLOGUE) {
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < pro.n_zero; i += 256) pro.zero[i] = 0u;
+    }
+    if ((int)threadIdx.x < n_here) {
+        const int64_t pt = p0 + threadIdx.x;
+        if constexpr (PROLOGUE) {
+            const int64_t ray = pt / S;
+            const float zz = stratified_z(rays[ray * ray_ld + 6], rays[ray * ray_ld + 7], (int)(pt - ray * S), S, pro.lindisp,
+                                          pro.t_rand ? pro.t_rand + pt : nullptr);
+            z[pt] = zz;
+            sz[threadIdx.x] = zz;
+        } else {
+            sz[threadIdx.x] = z[pt];
+        }
+    }
+    __syncthreads();
     for (int it = threadIdx.x; it < kEmbedPoints * 3 * fx; it += 256) {
         const int pl = it / (3 * fx), c = (it / fx) % 3, k = it % fx - 1;
         if (pl >= n_here) continue;
         const int64_t pt = p0 + pl;
         const float* r = rays + (pt / S) * ray_ld;
-        const float p = __fadd_rn(r[c], __fmul_rn(r[3 + c], z[pt]));   // nerf.ipynb:447
+        const float p = __fadd_rn(r[c], __fmul_rn(r[3 + c], sz[pl]));   // nerf.ipynb:447
         if (k < 0) {
             sx[pl][c] = p;
         } else {
@@ -693,8 +723,61 @@ hipError_t launch_embed_train(const float* rays, int ray_ld, const float* z, int
                               float* x0, int ld0, float* x1, int ld1, float* vcat, int ldv, int voff, hipStream_t s) {
     if (P <= 0) return hipSuccess;
     if (Lx < 0 || Lx > 10 || Lv < 0 || Lv > 4 || !x0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(embed_train_kernel, dim3((unsigned)((P + kEmbedPoints - 1) / kEmbedPoints)), dim3(256), 0, s, rays,
-                       ray_ld, z, P, S, Lx, Lv, x0, ld0, x1, ld1, vcat, ldv, voff);
+    hipLaunchKernelGGL(embed_train_kernel<false>, dim3((unsigned)((P + kEmbedPoints - 1) / kEmbedPoints)), dim3(256), 0, s, rays,
+                       ray_ld, const_cast<float*>(z), P, S, Lx, Lv, x0, ld0, x1, ld1, vcat, ldv, voff, EmbedPrologue{});
+    return hipGetLastError();
+}
+
+hipError_t launch_train_prologue(const float* rays, int ray_ld, int64_t N, int S, int lindisp, const float* t_rand, float* z,
+                                 int Lx, int Lv, float* x0, int ld0, float* x1, int ld1, float* vcat, int ldv, int voff,
+                                 unsigned* zero, int n_zero, hipStream_t s) {
+    const int64_t P = N * S;
+    if (P <= 0) return hipSuccess;
+    if (Lx < 0 || Lx > 10 || Lv < 0 || Lv > 4 || !x0 || !z) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(embed_train_kernel<true>, dim3((unsigned)((P + kEmbedPoints - 1) / kEmbedPoints)), dim3(256), 0, s, rays,
+                       ray_ld, z, P, S, Lx, Lv, x0, ld0, x1, ld1, vcat, ldv, voff, EmbedPrologue{t_rand, lindisp, zero, n_zero});
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// MID (between the passes): raw2outputs of the coarse pass and the resampling it feeds - composite_ray, then sample_pdf_ray
+// on the weights the same wavefront has just written (nerf.ipynb:452-467) - one workgroup of 64 per ray, one launch for two.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void train_mid_kernel(const float* __restrict__ raw, int C, const float* __restrict__ z_c,
+                                                       const float* __restrict__ rays_d, int d_ld,
+                                                       const float* __restrict__ noise, int white_bkgd, int S,
+                                                       float* __restrict__ rgb_c, float* __restrict__ w_c,
+                                                       const float* __restrict__ u, int n_samples, int n_sort,
+                                                       float* __restrict__ z_f) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t ray = blockIdx.x;
+    composite_ray(ray, threadIdx.x, raw, C, z_c, rays_d, d_ld, noise, white_bkgd, S, rgb_c, nullptr, nullptr, w_c, nullptr);
+    __threadfence_block();
+    __syncthreads();      // (one wavefront: the weights it wrote are what it reads next)
+    sample_pdf_ray(ray, threadIdx.x, smem, nullptr, w_c, S, 1, z_c, u, S - 1, n_samples, n_sort, nullptr, z_f, nullptr);
+}
+
+hipError_t launch_train_mid(const float* raw, int C, const float* z_c, const float* rays_d, int d_ld, const float* noise,
+                            int white_bkgd, int64_t N, int S, float* rgb_c, float* w_c, const float* u, int n_samples,
+                            float* z_f, hipStream_t s) {
+    if (N <= 0) return hipSuccess;
+    if (N > 0x7fffffffLL || S < 3) return hipErrorInvalidValue;
+    const int M = S - 1;
+    int n_sort = 2;
+    while (n_sort < M + 1 + n_samples) n_sort <<= 1;
+    const size_t lds = sizeof(float) * (size_t)(2 * M + n_sort);
+    static size_t raised[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (lds > 48 * 1024 && lds > raised[dev]) {
+        e = hipFuncSetAttribute((const void*)train_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised[dev] = lds;
+    }
+    hipLaunchKernelGGL(train_mid_kernel, dim3((unsigned)N), dim3(64), lds, s, raw, C, z_c, rays_d, d_ld, noise, white_bkgd, S,
+                       rgb_c, w_c, u, n_samples, n_sort, z_f);
     return hipGetLastError();
 }
 
@@ -758,73 +841,8 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
                                                            const float* __restrict__ g_rgb, float* __restrict__ d_raw) {
     extern __shared__ float Tsh[];   // exclusive transmittance of every sample of this ray
     const int64_t ray = blockIdx.x;
-    const int lane = threadIdx.x;
-    const float* d = rays_d + ray * d_ld;
-    const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
-    const float* z = z_vals + ray * S;
-    const float* rw = raw + ray * (int64_t)S * C;
-    float* dr = d_raw + ray * (int64_t)S * C;
-    const float g0 = g_rgb[ray * 3 + 0], g1 = g_rgb[ray * 3 + 1], g2 = g_rgb[ray * 3 + 2];
-    const float gbg = white_bkgd ? (g0 + g1 + g2) : 0.0f;
-
-    auto alpha_at = [&](int i, float& dist, float& sig) {
-        dist = __fmul_rn(i < S - 1 ? __fsub_rn(z[i + 1], z[i]) : 1e10f, norm);
-        sig = rw[(int64_t)i * C + 3];
-        if (noise) sig = __fadd_rn(sig, noise[ray * S + i]);
-        return __fsub_rn(1.0f, expf(__fmul_rn(-fmaxf(sig, 0.0f), dist)));
-    };
-    // forward pass: T_i exactly as the forward kernel computes it (fp64 scan, each prefix rounded to fp32)
-    double carry_t = 1.0;
-    for (int base = 0; base < S; base += 64) {
-        const int i = base + lane;
-        float dist, sig;
-        const float alpha = i < S ? alpha_at(i, dist, sig) : 0.0f;
-        double v = i < S ? (double)__fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f) : 1.0;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const double nb = __shfl_up(v, o);
-            if (lane >= o) v *= nb;
-        }
-        double excl = __shfl_up(v, 1);
-        if (lane == 0) excl = 1.0;
-        if (i < S) Tsh[i] = (float)(carry_t * excl);
-        carry_t *= __shfl(v, 63);
-    }
-    __syncthreads();
-    // backward pass from the far end; carry = sum over samples beyond this round of w_i (g.c_i - gbg)
-    float carry = 0.0f;
-    for (int rd = (S + 63) / 64 - 1; rd >= 0; --rd) {
-        const int i = rd * 64 + lane;
-        const bool on = i < S;
-        float wi = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, alpha = 0.0f, dist = 0.0f, sig = 0.0f, T = 0.0f;
-        if (on) {
-            alpha = alpha_at(i, dist, sig);
-            T = Tsh[i];
-            wi = __fmul_rn(alpha, T);
-            c0 = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw[(int64_t)i * C + 0])));
-            c1 = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw[(int64_t)i * C + 1])));
-            c2 = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw[(int64_t)i * C + 2])));
-        }
-        const float gc = g0 * c0 + g1 * c1 + g2 * c2;
-        const float q = on ? wi * (gc - gbg) : 0.0f;
-        float incl = q;   // inclusive suffix sum over lanes (from lane 63 down)
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const float nb = __shfl_down(incl, o);
-            if (lane + o < 64) incl += nb;
-        }
-        const float suffix_excl = incl - q + carry;   // sum_{i' > i} w_i' (g.c_i' - gbg)
-        carry += __shfl(incl, 0);
-        if (on) {
-            const float om = __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f);
-            const float dalpha_dsig = sig > 0.0f ? dist * (1.0f - alpha) : 0.0f;   // d/dsigma of 1 - exp(-relu(sigma) dist)
-            dr[(int64_t)i * C + 0] = g0 * wi * c0 * (1.0f - c0);
-            dr[(int64_t)i * C + 1] = g1 * wi * c1 * (1.0f - c1);
-            dr[(int64_t)i * C + 2] = g2 * wi * c2 * (1.0f - c2);
-            dr[(int64_t)i * C + 3] = dalpha_dsig * (T * (gc - gbg) - suffix_excl / om);
-            for (int c = 4; c < C; ++c) dr[(int64_t)i * C + c] = 0.0f;
-        }
-    }
+    composite_bwd_ray(ray, threadIdx.x, Tsh, raw, C, z_vals, rays_d, d_ld, noise, white_bkgd, S, g_rgb[ray * 3 + 0],
+                      g_rgb[ray * 3 + 1], g_rgb[ray * 3 + 2], d_raw);
 }
 
 hipError_t launch_composite_bwd(const float* raw, int C, const float* z, const float* rays_d, int d_ld,
@@ -833,6 +851,107 @@ hipError_t launch_composite_bwd(const float* raw, int C, const float* z, const f
     if (N <= 0) return hipSuccess;
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)N), dim3(64), (size_t)S * sizeof(float), s, raw, C, z,
                        rays_d, d_ld, noise, white_bkgd, S, g_rgb, d_raw);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// EPILOGUE of the forward direction and first launch of the backward one: raw2outputs of the LAST pass (composite_ray),
+// both MSE losses with their gradients (the expressions of mse_partial_kernel / mse_final_kernel), and the backward of
+// raw2outputs for the last pass and - when there are two - the coarse one (composite_bwd_ray): one workgroup of 64 per ray.
+// The loss VALUES need every ray: each workgroup leaves its ray's two sums of squares (double) and takes a ticket; the last
+// one adds all of them up in index order (the same sums whichever workgroup that is), divides, and writes the losses, their
+// sum and the two PSNRs (mse2psnr, nerf_helpers.py:14: -10 log(x) / log(10), rounded like the three tensor operations the
+// Python mirror used to spend on it). One launch where there were eight, and three device-to-device copies less.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void train_epilogue_kernel(const TrainEpilogue e) {
+    extern __shared__ float Tsh[];
+    __shared__ float rgb_sh[3];
+    __shared__ int last_sh;
+    const int64_t ray = blockIdx.x;
+    const int lane = threadIdx.x;
+    float rgb[3] = {0.0f, 0.0f, 0.0f};
+    composite_ray(ray, lane, e.raw_l, e.C_l, e.z_l, e.rays_d, e.d_ld, e.noise_l, e.white_bkgd, e.S_l, e.out_rgb, nullptr, nullptr,
+                  nullptr, nullptr, rgb);
+    if (lane == 0) {
+        rgb_sh[0] = rgb[0];
+        rgb_sh[1] = rgb[1];
+        rgb_sh[2] = rgb[2];
+    }
+    __syncthreads();
+    const float scale = 2.0f / (float)(e.N * 3);
+    const float t0 = e.target[ray * 3 + 0], t1 = e.target[ray * 3 + 1], t2 = e.target[ray * 3 + 2];
+    const float d0 = __fsub_rn(rgb_sh[0], t0), d1 = __fsub_rn(rgb_sh[1], t1), d2 = __fsub_rn(rgb_sh[2], t2);
+    double sq_l = (double)__fmul_rn(d0, d0) + (double)__fmul_rn(d1, d1) + (double)__fmul_rn(d2, d2), sq_c = 0.0;
+    composite_bwd_ray(ray, lane, Tsh, e.raw_l, e.C_l, e.z_l, e.rays_d, e.d_ld, e.noise_l, e.white_bkgd, e.S_l,
+                      __fmul_rn(scale, d0), __fmul_rn(scale, d1), __fmul_rn(scale, d2), e.d_raw_l);
+    if (e.raw_c) {
+        const float c0 = e.rgb_c[ray * 3 + 0], c1 = e.rgb_c[ray * 3 + 1], c2 = e.rgb_c[ray * 3 + 2];
+        const float f0 = __fsub_rn(c0, t0), f1 = __fsub_rn(c1, t1), f2 = __fsub_rn(c2, t2);
+        sq_c = (double)__fmul_rn(f0, f0) + (double)__fmul_rn(f1, f1) + (double)__fmul_rn(f2, f2);
+        if (lane < 3 && e.out_rgb0) e.out_rgb0[ray * 3 + lane] = e.rgb_c[ray * 3 + lane];
+        __syncthreads();      // (Tsh is reused)
+        composite_bwd_ray(ray, lane, Tsh, e.raw_c, e.C_c, e.z_c, e.rays_d, e.d_ld, e.noise_c, e.white_bkgd, e.S_c,
+                          __fmul_rn(scale, f0), __fmul_rn(scale, f1), __fmul_rn(scale, f2), e.d_raw_c);
+    }
+    // ---- the loss values: the last workgroup to arrive adds the rays' sums up ----
+    if (lane == 0) {
+        e.part[ray] = sq_l;
+        e.part[e.N + ray] = sq_c;
+        __threadfence();
+        last_sh = atomicAdd(e.ticket, 1u) == (unsigned)(e.N - 1);
+    }
+    __syncthreads();
+    if (!last_sh) return;
+    __threadfence();
+    double s_l = 0.0, s_c = 0.0;
+    for (int64_t i = lane; i < e.N; i += 64) {
+        s_l += __builtin_nontemporal_load(e.part + i);
+        s_c += __builtin_nontemporal_load(e.part + e.N + i);
+    }
+    s_l = wsum(s_l);
+    s_c = wsum(s_c);
+    if (lane == 0) {
+        const double n = (double)(e.N * 3);
+        const float loss_l = (float)(s_l / n), loss_c = (float)(s_c / n);
+        const float inv_ln10 = __fdiv_rn(1.0f, 2.302585092994046f);       // (torch divides by a Python scalar as x * (1 / s))
+        e.loss_dev[0] = loss_l;
+        if (e.out_loss) e.out_loss[0] = loss_l;
+        if (e.raw_c) {
+            e.loss_dev[1] = loss_c;
+            if (e.out_loss) e.out_loss[1] = loss_c;
+        }
+        if (e.out_stats) {      // img_loss, img_loss0, loss, psnr, psnr0
+            e.out_stats[0] = loss_l;
+            e.out_stats[1] = e.raw_c ? loss_c : 0.0f;
+            e.out_stats[2] = e.raw_c ? __fadd_rn(loss_l, loss_c) : loss_l;
+            e.out_stats[3] = __fmul_rn(__fmul_rn(logf(loss_l), -10.0f), inv_ln10);
+            e.out_stats[4] = e.raw_c ? __fmul_rn(__fmul_rn(logf(loss_c), -10.0f), inv_ln10) : 0.0f;
+        }
+        *e.ticket = 0u;      // for the next step (the prologue zeroes it as well)
+    }
+}
+
+// (legacy glue: the same five numbers from the two losses the MSE kernels left)
+__global__ void train_stats_kernel(const float* __restrict__ loss, int two, float* __restrict__ stats) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float inv_ln10 = __fdiv_rn(1.0f, 2.302585092994046f);
+    const float l = loss[0], c = two ? loss[1] : 0.0f;
+    stats[0] = l;
+    stats[1] = c;
+    stats[2] = two ? __fadd_rn(l, c) : l;
+    stats[3] = __fmul_rn(__fmul_rn(logf(l), -10.0f), inv_ln10);
+    stats[4] = two ? __fmul_rn(__fmul_rn(logf(c), -10.0f), inv_ln10) : 0.0f;
+}
+hipError_t launch_train_stats(const float* loss, bool two, float* stats, hipStream_t s) {
+    hipLaunchKernelGGL(train_stats_kernel, dim3(1), dim3(64), 0, s, loss, two ? 1 : 0, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_train_epilogue(const TrainEpilogue& e, hipStream_t s) {
+    if (e.N <= 0) return hipSuccess;
+    if (e.N > 0x7fffffffLL || !e.part || !e.ticket || !e.loss_dev) return hipErrorInvalidValue;
+    const int S = e.S_l > e.S_c ? e.S_l : e.S_c;
+    hipLaunchKernelGGL(train_epilogue_kernel, dim3((unsigned)e.N), dim3(64), (size_t)S * sizeof(float), s, e);
     return hipGetLastError();
 }
 

@@ -1150,10 +1150,9 @@ def train_on_batch(H, W, K, batch_rays, target_s, optimizer, chunk=1024 * 32, nd
         raise TypeError("train_on_batch needs this package's NeRF models")
     ctx = network_fn.ctx
     if _packed_rays is not None:      # (tests: a ray record exactly as the reference's render() packed it, e.g. NDC-warped)
-        packed = _dev(_packed_rays, ctx)
+        packed = _dev(_packed_rays, ctx).contiguous()
     else:
-        packed, _ = pack_rays(H, W, K, batch_rays, None, ndc, near, far, use_viewdirs, None, device=ctx.device)
-    packed = packed.contiguous()
+        packed = _pack_batch(ctx, H, W, K, batch_rays, ndc, near, far, use_viewdirs)
     target = _dev(target_s, ctx).reshape(-1, 3)
     N, stride = packed.shape
     if target.shape[0] != N:
@@ -1168,47 +1167,85 @@ def train_on_batch(H, W, K, batch_rays, target_s, optimizer, chunk=1024 * 32, nd
     a.lindisp, a.white_bkgd = int(bool(lindisp)), int(bool(white_bkgd))
     keep = [packed, target]
     perturb = float(perturb)
-
-    def draw(shape, normal=False):            # the reference's RNG order, incl. its pytest re-seeding
-        if pytest:
+    try:
+        noise_std = float(raw_noise_std)      # YAML may hand over the string '1e0'
+    except (TypeError, ValueError):
+        noise_std = 0.0
+    n_c, n_i, n_f = N * Sc, (N * Si if Si > 0 else 0), (N * (Sc + Si) if Si > 0 else 0)
+    if pytest:                                # the reference's RNG order, incl. its re-seeding before every draw
+        def draw(shape):
             np.random.seed(0)
             return _dev(np.random.rand(*shape), ctx)
-        return torch.randn(shape, **o) if normal else torch.rand(shape, **o)
-
+        t_rand = draw((N, Sc)) if perturb > 0. else None
+        n0 = _noise((N, Sc), raw_noise_std, pytest, ctx)
+        u = draw((N, Si)) if perturb > 0. and Si > 0 else None
+        n1 = _noise((N, Sc + Si), raw_noise_std, pytest, ctx) if Si > 0 else None
+    else:
+        # every uniform of the iteration in ONE draw and every normal in another (t_rand | u and noise0 | noise as the two
+        # halves of a flat buffer: the same distributions as the reference's four draws, two launches instead of four)
+        t_rand = u = n0 = n1 = None
+        if perturb > 0.:
+            uni = torch.rand(n_c + n_i, **o)
+            t_rand, u = uni[:n_c].view(N, Sc), (uni[n_c:].view(N, Si) if Si > 0 else None)
+        if noise_std > 0.0:
+            nrm = torch.randn(n_c + n_f, **o)
+            if noise_std != 1.0:              # (every YAML of the reference has raw_noise_std 1e0: x * 1 = x)
+                nrm = nrm * noise_std
+            n0, n1 = nrm[:n_c].view(N, Sc), (nrm[n_c:].view(N, Sc + Si) if Si > 0 else None)
     if perturb > 0.:
         a.perturb = 1
-        t_rand = draw((N, Sc))
-        keep.append(t_rand)
-        a.t_rand = t_rand.data_ptr()
-    n0 = _noise((N, Sc), raw_noise_std, pytest, ctx)
-    if n0 is not None:
-        keep.append(n0)
-        a.noise0 = n0.data_ptr()
-    if Si > 0:
-        if perturb > 0.:
-            u = draw((N, Si))
-            keep.append(u)
-            a.u_rand = u.data_ptr()
-        n1 = _noise((N, Sc + Si), raw_noise_std, pytest, ctx)
-        if n1 is not None:
-            keep.append(n1)
-            a.noise = n1.data_ptr()
+    for name, t in (("t_rand", t_rand), ("noise0", n0), ("u_rand", u), ("noise", n1)):
+        if t is not None:
+            keep.append(t)
+            setattr(a, name, t.data_ptr())
     g = optimizer.param_groups[0]
     a.lr, (a.beta1, a.beta2), a.eps = g['lr'], g['betas'], g['eps']
     a.apply_update = int(bool(apply_update))
     if apply_update:
         optimizer.steps += 1
     a.step = max(optimizer.steps, 1)
-    loss = torch.zeros(2, **o)
+    # img_loss, img_loss0, loss, psnr, psnr0 (nerf.ipynb:1262-1272) come back as five numbers of one device array: no tensor
+    # operation per number on this side (mse2psnr's log / multiply / divide and the sum of the losses were four launches)
+    stats = torch.empty(5, **o)
     rgb = torch.empty((N, 3), **o)
     rgb0 = torch.empty((N, 3), **o) if Si > 0 else None
-    a.loss, a.rgb_map, a.rgb0 = loss.data_ptr(), rgb.data_ptr(), (rgb0.data_ptr() if Si > 0 else None)
+    a.stats, a.rgb_map, a.rgb0 = stats.data_ptr(), rgb.data_ptr(), (rgb0.data_ptr() if Si > 0 else None)
     a.stream = ctx.stream().value
     check(ctx.lib.nerf_train_step(ctx.handle, C.byref(a)))
-    psnr = mse2psnr(loss)      # (both at once: element-wise, the same values as one call per loss)
-    out = {'img_loss': loss[0], 'psnr': psnr[0], 'rgb': rgb, 'loss': loss[0]}
+    out = {'img_loss': stats[0], 'psnr': stats[3], 'rgb': rgb, 'loss': stats[2]}
     if Si > 0:
-        out.update(img_loss0=loss[1], psnr0=psnr[1], rgb0=rgb0, loss=loss[0] + loss[1])
+        out.update(img_loss0=stats[1], psnr0=stats[4], rgb0=rgb0)
+    return out
+
+
+def _pack_batch(ctx, H, W, K, rays, ndc, near, far, use_viewdirs):
+    """``render(H, W, K, rays=batch_rays, ...)``'s packing of a ray batch (nerf.ipynb:596-629) in ONE kernel
+    (``nerf_pack_rays``): unit viewing directions before the NDC warp, ``ndc_rays(H, W, K[0][0], 1., ...)``, near / far
+    columns. ``rays`` is the ``(rays_o, rays_d)`` pair or the stacked ``[2, N, 3]`` tensor; rows may be strided views."""
+    rays_o, rays_d = rays
+    sh = tuple(rays_d.shape)
+
+    def rows(t):
+        if not torch.is_tensor(t):
+            t = torch.as_tensor(np.asarray(t))
+        t = t.detach().to(device=ctx.device, dtype=torch.float32).reshape(-1, 3) if t.dim() != 2 else \
+            t.detach().to(device=ctx.device, dtype=torch.float32)
+        if t.stride(1) != 1 or t.stride(0) < 3:
+            t = t.contiguous()
+        return t
+
+    ro, rd = rows(rays_o), rows(rays_d)
+    if ro.shape != rd.shape or ro.shape[-1] != 3:
+        raise RuntimeError(f"rays_o {tuple(ro.shape)} and rays_d {tuple(rd.shape)} must both be [N, 3]")
+    cam = Camera()
+    cam.H, cam.W = int(H), int(W)
+    cam.ndc = int(bool(ndc))
+    cam.ndc_focal = float(K[0][0]) if ndc else 0.0
+    cam.near, cam.far, cam.use_viewdirs = float(near), float(far), int(bool(use_viewdirs))
+    n = ro.shape[0]
+    out = torch.empty((n, 11 if use_viewdirs else 8), device=ctx.device, dtype=torch.float32)
+    check(ctx.lib.nerf_pack_rays(ctx.handle, C.byref(cam), _ptr(ro), ro.stride(0), _ptr(rd), rd.stride(0), n, _ptr(out),
+                                 ctx.stream()))
     return out
 
 
