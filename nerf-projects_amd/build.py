@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnerf_mi355x.so")
 SOURCES = ["api.cpp", "train_api.cpp", "pack_weights.cpp", "mlp_kernel.hip", "mlp_kernel_h2.hip", "mlp_bwd_kernel_h2.hip",
-           "ray_kernels.hip", "train_kernels.hip", "train_dw_kernel.hip"]
+           "ray_kernels.hip", "train_kernels.hip", "train_dw_kernel.hip", "refresh_kernels.hip"]
 HEADERS = [os.path.join(CSRC, "nerf_internal.h"), os.path.join(CSRC, "ctx_internal.h"),
            os.path.join(CSRC, "mlp_inputs.h"), os.path.join(CSRC, "mlp_pair_common.h"), os.path.join(CSRC, "ray_device.h"),
            os.path.join(ROOT, "include", "nerf_mi355x.h")]

@@ -312,6 +312,7 @@ int nerf_ctx_create(int device, nerf_ctx** out) {
         if (e2 == hipSuccess) e2 = hipMemset(c->d_loose, 0, kLooseWords * sizeof(unsigned));
         if (e2 == hipSuccess) e2 = hipHostMalloc((void**)&c->h_loose, kLooseWords * sizeof(unsigned), hipHostMallocDefault);
         if (e2 == hipSuccess) memset(c->h_loose, 0, kLooseWords * sizeof(unsigned));
+        if (e2 == hipSuccess && hipHostGetDevicePointer((void**)&c->h_loose_dev, c->h_loose, 0) != hipSuccess) c->h_loose_dev = nullptr;
         if (e2 != hipSuccess) {
             set_error("nerf_ctx_create: device allocation failed: %s", hipGetErrorString(e2));
             delete c;

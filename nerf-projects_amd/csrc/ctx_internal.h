@@ -30,6 +30,7 @@ struct nerf_ctx {
     // word kLooseTrain, and each has its own cursor of what has been reported (`loose_seen`, `train_loose_seen`): a frame
     // rendered after a loose training step does not take that step's events, nor the other way round.
     unsigned* h_loose = nullptr;
+    unsigned* h_loose_dev = nullptr;   // the mirror's address as the device sees it (kernels may write it: refresh_kernels.hip)
     unsigned loose_seen = 0;
     unsigned train_loose_seen = 0;
     bool train_force_f32 = false;  // set by nerf_train_step when it sees new events: training continues on the fp32 kernels

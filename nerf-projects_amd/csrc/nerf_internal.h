@@ -67,6 +67,7 @@ struct TrainState {
     int n_chunks_bwd = 0;
     bool bwd_dirty = true;           // the master parameters changed since d_stream_bwd (and its fp16-pair twin) were made
     bool bwd_is_eq = false;          // what d_stream_bwd currently holds
+    bool bwd_is_pair = false;        // ... and whether its fp16-pair twin and gains were made with it
     // fp16-pair twin of d_stream_bwd (mlp_bwd_kernel_h2.hip): one scale group per transposed matrix, the gains bound a
     // layer's input gradient from its output gradient: [largest row sum of |W^T|, largest |alpha weight| (layer 1 only)]
     uint32_t* d_stream_bwd_h2 = nullptr;
@@ -267,6 +268,38 @@ int refresh_h2_many(PackedNet* const* nets, int n, hipStream_t s);
 int refresh_f32(PackedNet& net, hipStream_t s);
 hipError_t launch_convert_stream_h2(const float* stream, const int* chunk_layer, int n_chunks, float* chunk_max,
                                     uint32_t* out, float* descale, hipStream_t s);
+// Everything the fp16-pair kernels read, rebuilt after an optimiser step in two launches (refresh_kernels.hip): up to four
+// streams (two networks x forward / backward-data), their bias blocks and gain tables
+struct RefreshStream {
+    const float* params;      // the (row-equalised) parameters the stream is cut from
+    const int* table;         // stream element -> parameter index, or -1
+    float* stream;            // fp32 stream (n_chunks x kChunkFloats)
+    float* chunk_max;         // [n_chunks]
+    const int* chunk_layer;   // scale group of every chunk
+    uint32_t* out_h2;         // fp16-pair stream ((n_chunks + kStreamTailChunks) x kChunkFloats words)
+    float* descale;           // per scale group
+    int n_chunks;
+};
+struct RefreshBias {
+    const float* params;
+    const int* table;
+    float* out;
+    int n;
+};
+struct RefreshBatch {
+    int n_streams, n_bias, n_gain, n_bgain;
+    RefreshStream st[4];
+    RefreshBias bias[2];
+    const float* gain_params[2];
+    GainRefs gain[2];
+    float* gain_out[2];
+    const float* bgain_params[2];
+    BwdGainRefs bgain[2];
+    float* bgain_out[2];
+    const unsigned* mirror_src;   // nerf_ctx::d_loose -> its host mirror (device-visible address), or nullptr
+    unsigned* mirror_dst;
+};
+hipError_t launch_refresh(const RefreshBatch& b, hipStream_t s);
 hipError_t launch_embed(const float* x, int64_t n, int multires, float* out, hipStream_t s);
 hipError_t launch_stratified(const float* rays, int ray_ld, int64_t N, int S, int lindisp,
                              const float* t_rand, float* z_vals, hipStream_t s);

@@ -150,8 +150,14 @@ __device__ __forceinline__ void cam_ray(const float* c2w, float fx, float fy, fl
 
 // what render() does to a ray (o, d) between get_rays and the chunk loop (nerf.ipynb:600-629): the unit viewing direction,
 // taken BEFORE the NDC warp, then ndc_rays (nerf_helpers.py:311-369, called with near = 1.0)
+// TORCH_GPU_ORDER: torch.norm(d, dim=-1) on the device adds the squares as (x^2 + z^2) + y^2 (two accumulators over the row;
+// tools/gpu/norm_probe.py: 0 of 2^20 rows differ, every other order 10 % of them) - what the training loop's batches went
+// through while host.pack_rays packed them with tensor operations, and what nerf_pack_rays reproduces bit for bit; the frame
+// path (raygen_kernel) keeps the left-to-right sum its fixtures from the reference's CPU run were checked with.
+template <bool TORCH_GPU_ORDER = false>
 __device__ __forceinline__ void unit_direction(const float (&d)[3], float (&v)[3]) {
-    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+    const float xx = __fmul_rn(d[0], d[0]), yy = __fmul_rn(d[1], d[1]), zz = __fmul_rn(d[2], d[2]);
+    const float nrm = sqrtf(TORCH_GPU_ORDER ? __fadd_rn(__fadd_rn(xx, zz), yy) : __fadd_rn(__fadd_rn(xx, yy), zz));
 #pragma unroll
     for (int k = 0; k < 3; ++k) v[k] = __fdiv_rn(d[k], nrm);
 }
@@ -203,7 +209,7 @@ __global__ void pack_rays_kernel(const float* __restrict__ rays_o, int o_ld, con
     float o[3] = {rays_o[t * o_ld], rays_o[t * o_ld + 1], rays_o[t * o_ld + 2]};
     float d[3] = {rays_d[t * d_ld], rays_d[t * d_ld + 1], rays_d[t * d_ld + 2]};
     float v[3] = {0.0f, 0.0f, 0.0f};
-    if (use_viewdirs) unit_direction(d, v);
+    if (use_viewdirs) unit_direction<true>(d, v);
     if (ndc) ndc_warp(ndc_cw, ndc_ch, o, d);
     write_ray_record(rays + t * (use_viewdirs ? 11 : 8), o, d, v, near, far, use_viewdirs != 0);
 }

@@ -73,6 +73,7 @@ int refresh_bwd(PackedNet& net, bool eq, bool pair, hipStream_t s) {
     if (!t.bwd_dirty && t.bwd_is_eq == eq && (!pair || have_pair)) return NERF_OK;
     HIP_TRY(launch_gather(eq ? net.d_params_eq : net.d_params, t.d_bwd_table, (int64_t)net.bwd_table.size(), t.d_stream_bwd, s));
     t.bwd_is_eq = eq;
+    t.bwd_is_pair = pair;
     if (pair) {
         const int nb = t.n_chunks_bwd;
         if (!have_pair) {
@@ -110,6 +111,57 @@ int refresh_bwd(PackedNet& net, bool eq, bool pair, hipStream_t s) {
                                        t.d_gain_bwd, s));
     }
     t.bwd_dirty = false;
+    return NERF_OK;
+}
+
+// After an optimiser step, in four launches instead of eleven per network and direction (refresh_kernels.hip): the
+// row-equalised copies (row_exponents + apply), then every stream the fp16-pair kernels read - the forward ones and, where the
+// backward-data kernel has run on them, the transposed ones - with their bias blocks and gains, and the precision guard's
+// counters to their host mirror. What refresh_h2_many + refresh_bwd(eq, pair) + mirror_loose do stage by stage.
+int refresh_after_step(nerf_ctx* c, PackedNet* const* nets, int n, hipStream_t s, bool* mirrored) {
+    const float* params[2];
+    float* out[2];
+    int* rexp[2];
+    EqualiseRefs refs[2];
+    if (n < 1 || n > 2) return NERF_E_INVALID;
+    for (int i = 0; i < n; ++i) {
+        params[i] = nets[i]->d_params;
+        out[i] = nets[i]->d_params_eq;
+        rexp[i] = nets[i]->d_row_exp;
+        refs[i] = equalise_refs(nets[i]->arch, nets[i]->linears);
+    }
+    HIP_TRY(launch_equalise_rows(n, params, refs, out, rexp, s));
+    RefreshBatch b{};
+    for (int i = 0; i < n; ++i) {
+        PackedNet& net = *nets[i];
+        TrainState& t = net.train;
+        b.st[b.n_streams++] = RefreshStream{net.d_params_eq, t.d_stream_table, net.d_stream_eq, net.d_chunk_max, net.d_chunk_layer,
+                                            net.d_stream_h2, net.d_descale, net.n_chunks};
+        b.bias[b.n_bias++] = RefreshBias{net.d_params_eq, t.d_bias_table, net.d_bias_h2, (int)net.bias_table.size()};
+        b.gain_params[b.n_gain] = net.d_params_eq;
+        b.gain[b.n_gain] = gain_refs(net.arch, net.linears);
+        b.gain_out[b.n_gain++] = net.d_gain;
+        // the backward-data stream, when the fp16-pair backward kernel has been running on the equalised transposed weights
+        const bool bwd = t.d_stream_bwd && t.d_stream_bwd_h2 && t.d_descale_bwd && t.d_gain_bwd && t.d_chunk_layer_bwd &&
+                         t.d_chunk_max_bwd && t.bwd_is_eq && t.bwd_is_pair;
+        if (bwd) {
+            b.st[b.n_streams++] = RefreshStream{net.d_params_eq, t.d_bwd_table, t.d_stream_bwd, t.d_chunk_max_bwd,
+                                                t.d_chunk_layer_bwd, t.d_stream_bwd_h2, t.d_descale_bwd, t.n_chunks_bwd};
+            b.bgain_params[b.n_bgain] = net.d_params_eq;
+            b.bgain[b.n_bgain] = bwd_gain_refs(net.arch, net.linears, net.skip_in_mask);
+            b.bgain_out[b.n_bgain++] = t.d_gain_bwd;
+            t.bwd_dirty = false;
+        } else {
+            t.bwd_dirty = true;      // (rebuilt by refresh_bwd when a backward pass next wants it)
+        }
+        net.h2_dirty = false;
+    }
+    if (c->h_loose_dev && (c->precision == NERF_PRECISION_F16X2 || c->train_precision == NERF_PRECISION_F16X2)) {
+        b.mirror_src = c->d_loose;
+        b.mirror_dst = c->h_loose_dev;
+        *mirrored = true;
+    }
+    HIP_TRY(launch_refresh(b, s));
     return NERF_OK;
 }
 
@@ -1018,6 +1070,7 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     }
     }
     // ---- optimizer.step() (torch.optim.Adam, nerf.ipynb:905, :1275) ----
+    bool mirrored = false;
     if (r->apply_update) {
         if (r->step < 1) {
             set_error("nerf_train_step: step must be the 1-based Adam step count");
@@ -1034,10 +1087,12 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
         if (pc.eq) {
             PackedNet* both[2] = {&nc, &nf};
             const int n_nets = (Si && !shared) ? 2 : 1;
-            if ((rc = refresh_h2_many(both, n_nets, s))) return rc;
+            if (fused_glue) {
+                if ((rc = refresh_after_step(c, both, n_nets, s, &mirrored))) return rc;
+            } else if ((rc = refresh_h2_many(both, n_nets, s))) return rc;
         }
     }
-    HIP_TRY(mirror_loose(c, s));
+    if (!mirrored) HIP_TRY(mirror_loose(c, s));
     if (fell_back) {
         set_error("nerf_train_step: the fp16-pair kernels' output-scale bound was loose in an earlier step (some activations "
                   "kept fewer than 24 bits with these weights); training continues on the fp32 kernels");

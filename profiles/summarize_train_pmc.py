@@ -14,7 +14,8 @@ import sys
 
 import pandas as pd
 
-KERNELS = ["nerf_mlp_h2_kernel", "nerf_mlp_bwd_h2_kernel", "grad_batch_pair_kernel", "grad_batch_kernel", "row_exponents_kernel"]
+KERNELS = ["nerf_mlp_h2_kernel", "nerf_mlp_bwd_h2_kernel", "grad_batch_pair_dma_kernel", "grad_batch_pair_kernel", "grad_batch_kernel",
+           "row_exponents_kernel", "embed_train_kernel", "refresh_gather_kernel", "refresh_convert_kernel"]
 PREFIX = "train_pmc_"
 
 
@@ -62,6 +63,8 @@ def main(stem, root):
             rec["hbm_read_bytes_per_launch"], rec["hbm_read_bytes_per_launch_x2"], rec["hbm_write_bytes_per_launch"] = f, 2 * f, w
             if t:
                 rec["hbm_gb_per_s_uncorrected"], rec["hbm_gb_per_s_fetch_x2"] = (f + w) / t / 1e9, (2 * f + w) / t / 1e9
+        if "SQ_LDS_BANK_CONFLICT" in per and per.get("SQ_LDS_IDX_ACTIVE"):
+            rec["lds_bank_conflict_cycles_frac_of_lds_active"] = per["SQ_LDS_BANK_CONFLICT"] / per["SQ_LDS_IDX_ACTIVE"]
         if "TCC_HIT_sum" in per:
             rec["l2_hit_rate"] = per["TCC_HIT_sum"] / (per["TCC_HIT_sum"] + per["TCC_MISS_sum"])
         rec["counters_per_launch_mean"] = per

@@ -1466,27 +1466,30 @@ np.savez(out_path, **res)
 """
 
 
-@pytest.mark.parametrize("n_imp", [128, 0])
-def test_train_glue_is_bit_identical(N, n_imp, tmp_path):
-    """The training step's small stages as fused launches (prologue: depths + encodings + zeroing; mid: raw2outputs + resampling;
-    epilogue: raw2outputs, both losses, PSNRs and the backward of both raw2outputs) against the stage kernels they replace
-    (NERF_TRAIN_GLUE=legacy, which needs a process of its own: the switch is read once): two optimiser steps on the reference's
-    fixture batch - every loss, PSNR, colour, gradient and weight bit for bit."""
+@pytest.mark.parametrize("n_imp,switch", [(128, "NERF_TRAIN_GLUE=legacy"), (0, "NERF_TRAIN_GLUE=legacy"), (128, "NERF_TRAIN_BLOCKED=0")])
+def test_train_glue_is_bit_identical(N, n_imp, switch, tmp_path):
+    """Two optimiser steps on the reference's fixture batch, twice: as shipped, and with one of the step's A/B switches thrown
+    (each needs a process of its own: the switches are read once) - every loss, PSNR, colour, gradient and weight bit for bit.
+    NERF_TRAIN_GLUE=legacy: the step's small stages as the stage kernels they were (stratified depths, encodings, raw2outputs,
+    resampling, MSE, backward of raw2outputs; the refresh of the streams stage by stage) instead of the fused launches
+    (prologue / mid / epilogue / two refresh launches). NERF_TRAIN_BLOCKED=0: the kept activations and pre-activation gradients
+    row-major instead of blocked by 32 points - the same values in the same registers of the same kernels."""
     import subprocess
     import sys
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     precision = N.get_context().get_precision()
+    var, value = switch.split("=")
     results = {}
-    for mode in ("fused", "legacy"):
+    for mode in ("shipped", "switched"):
         env = dict(os.environ)
-        env.pop("NERF_TRAIN_GLUE", None)
-        if mode == "legacy":
-            env["NERF_TRAIN_GLUE"] = "legacy"
+        env.pop(var, None)
+        if mode == "switched":
+            env[var] = value
         path = str(tmp_path / f"{mode}.npz")
         subprocess.run([sys.executable, "-c", _GLUE_RUN, root, path, precision, str(n_imp)], check=True, env=env, timeout=600)
         results[mode] = np.load(path)
-    a, b = results["fused"], results["legacy"]
+    a, b = results["shipped"], results["switched"]
     assert sorted(a.files) == sorted(b.files) and len(a.files) > 50
     for k in a.files:
         assert np.array_equal(a[k], b[k], equal_nan=True), (k, np.abs(a[k].astype(np.float64) - b[k]).max())

@@ -17,10 +17,9 @@ for part in $parts; do
     python $P/summarize_pmc.py $R $M > /dev/null ;;
   train)
     cp $M/train_stats/*/*kernel_stats.csv $P/${R}_train_kernel_stats.csv
-    for f in bench_train bench_train_bwd_f32 bench_train_all_f32; do grep "^{" $M/$f.json > $P/${R}_$f.json; done
-    cp $M/points_per_wave.txt $P/${R}_points_per_wave.txt
-    python $P/summarize_train_pmc.py $P/${R}_train_pmc_summary $M > /dev/null
-    python $P/summarize_train_pmc.py $P/${R}_points_per_wave_pmc $M --prefix ppw_pmc_ --kernels "step_kernel<1>,step_kernel<2>" > /dev/null ;;
+    for f in bench_train bench_train_rowmajor bench_train_legacy_glue bench_train_noviewdirs bench_train_bwd_f32 bench_train_all_f32; do
+      [ -f $M/$f.json ] && grep "^{" $M/$f.json > $P/${R}_$f.json; done
+    python $P/summarize_train_pmc.py $P/${R}_train_pmc_summary $M > /dev/null ;;
   esac
 done
 python - "$R" <<'PY'
@@ -33,6 +32,8 @@ print("frame ms", round(d["ms_per_step"], 1), "samples/s %.3g" % d["value"], "fr
 t = d["train"]; print("train leg", round(t["value"], 1), {k: (round(v["ms_per_iter"], 3), round(v.get("frac_of_pipe_peak", 0), 3), v.get("hbm_gb_per_s")) for k, v in t["kernels"].items()})
 for f in ("bench_n1_f32", "bench_c1_lego400_coarse", "bench_c4_fern_ndc", "bench_n1_rccl_group"):
     e = last(f"profiles/{R}_{f}.json"); print(f, round(e["ms_per_step"], 1), "%.3g" % e["value"], round(e["roofline"]["frac"], 4), round(e["roofline"]["avg_launch_ms"], 3), (e.get("other_precision") or {}).get("ms_per_step"))
-for f in ("bench_train", "bench_train_bwd_f32", "bench_train_all_f32"):
-    e = last(f"profiles/{R}_{f}.json"); print(f, round(e["value"], 1), round(e["ms_per_iter"], 3))
+import os
+for f in ("bench_train", "bench_train_rowmajor", "bench_train_legacy_glue", "bench_train_noviewdirs", "bench_train_bwd_f32", "bench_train_all_f32"):
+    if os.path.exists(f"profiles/{R}_{f}.json"):
+        e = last(f"profiles/{R}_{f}.json"); print(f, round(e["value"], 1), round(e["ms_per_iter"], 3))
 PY
