@@ -99,6 +99,8 @@ __device__ __forceinline__ void bconvert_pairs(XT& dst, const f32x16& src, Pendi
         if constexpr (SPLIT) {
             bconv1(t, pd);
             conv_slice2<S>(dst, t);
+        } else {
+            pd.m = fmaxf(fmaxf(pd.m, fabsf(t.y0)), fabsf(t.y1));      // (d z_0: nothing follows, but its weight gradients scale by its size)
         }
         bconvert_pairs<T, S + 1, SPLIT, BLK>(dst, src, pd, even);
     }
@@ -278,7 +280,11 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
             // Into LDS (a per-lane atomic on eight global addresses, a quarter of all lanes firing, queued in the memory pipe
             // the weight ring's counted waits look at: it doubled the kernel's time); the workgroup adds its sums at the end.
             if (m_grp > 0.0f && slack >= 12 && pd.t_out > -60) {
+#ifdef NERF_LOOSE_BY_LAYER      // diagnostic build (tools/gpu/loose_probe.py): events of >= 2^24 by the slot they close, others in bucket 1
+                const int bucket = slack >= 24 ? 2 + (slot == kBwdMaxFeat ? 0 : (slot >= 6 ? 1 : (slot >= 3 ? 2 : (slot >= 1 ? 3 : 4)))) : 1;
+#else
                 const int bucket = 1 + (slack >= 24 ? 6 : (slack - 12) >> 1);
+#endif
                 const unsigned one = 1u;
                 asm volatile("ds_add_u32 %0, %1" : : "v"(lds_byte_addr(loose_hist + bucket)), "v"(one) : "memory");
                 if (slack >= kLooseBwdGuard) asm volatile("ds_add_u32 %0, %1" : : "v"(lds_byte_addr(loose_hist)), "v"(one) : "memory");
@@ -342,6 +348,7 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
         }
         // ---- d z_0: nothing follows to hide behind ----
         pd.keep_base = wave_uniform(b.out.h[0]) + (BLK ? 1024 : 0);      // (what make_pending(D) chose, as a value hipcc keeps in scalar registers)
+        pd.m = 0.0f;
         bconvert_tile<0, false, BLK>(hid[0], accA[0], pd);
         bconvert_tile<1, false, BLK>(hid[0], accA[1], pd);
         next_tile_pair<BLK>(pd);
@@ -353,6 +360,7 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
         next_tile_pair<BLK>(pd);
         bconvert_tile<6, false, BLK>(hid[0], accA[6], pd);
         bconvert_tile<7, false, BLK>(hid[0], accA[7], pd);
+        enter_max(&max_record[0], half_max(pd.m));
     }   // tile loop
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();

@@ -372,7 +372,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
     }
     prefetch_pieces<0, 4>(piece_src(pipe, 2), piece_dst(pipe, 2));   // chunk 0's first-half steps issue the other four
     for (int i = threadIdx.x; i < a.n_bias_tiles * kBiasTileFloats; i += 256) bias_lds[i] = a.bias[i];
-    if (STORE != 0 && threadIdx.x < kBwdMaxSlots) max_record[threadIdx.x] = 0u;
+    if (STORE != 0 && threadIdx.x < kBwdMaxSlots) max_record[threadIdx.x] = threadIdx.x == kBwdMaxGammaD ? 0x3f800000u : 0u;      // (|gamma(d)| <= 1)
     if (threadIdx.x < a.D + 3) {
         const int l = threadIdx.x;
         const bool has_gain = l <= (a.use_viewdirs ? a.D : a.D - 1);
@@ -415,6 +415,7 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
             // A wave's points share a ray or two, so the common scale costs the split nothing.
             m_pe = wave_max(tile_absmax(x1, tile_absmax(x0, 0.0f)));
             t_pe = pick_exponent(m_pe);
+            if constexpr (STORE != 0) enter_max(&max_record[kBwdMaxGammaX], m_pe);      // the gamma(x) columns' weight gradients scale by it
             split_tile(xp0, x0, pow2f(t_pe));
             split_tile(xp1, x1, pow2f(t_pe));
         }

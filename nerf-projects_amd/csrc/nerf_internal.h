@@ -207,6 +207,9 @@ struct MlpBwdLaunch {
     unsigned* maxes;
 };
 constexpr int kBwdMaxFeat = kMaxDepth, kBwdMaxViews = kMaxDepth + 1, kBwdMaxKept = 16, kBwdMaxFeatValue = 30, kBwdMaxSlots = 32;
+// entered by the fp16-pair forward pass for the gamma columns' weight gradients: the largest |gamma(x)| of the pass (the range
+// the kernel measures on its encoded inputs anyway) and 1.0 = the bound of gamma(d) (a unit vector, sines and cosines)
+constexpr int kBwdMaxGammaX = 28, kBwdMaxGammaD = 29;
 // kBwdMaxViews: d(view pre-activation); kBwdMaxFeatValue: the largest |feature| (entered by the fp16-pair forward pass)
 
 // host-side packer (pack_weights.cpp)
@@ -397,6 +400,7 @@ struct GradBatch {
 // pair: the wide jobs on the fp16 matrix pipe (every job needs a_max / b_max)
 hipError_t launch_grad_batch(GradBatch& b, bool wide, float* part, size_t part_floats, float* dbp, size_t dbp_floats,
                              hipStream_t s, bool pair = false);
+hipError_t launch_grad_batch_narrow_pair(GradBatch& b, float* part, size_t part_floats, float* dbp, size_t dbp_floats, hipStream_t s);
 // a rider row (GradJob::y) needs the LDS-prefetch kernel; its sums are added up into (dW_row [n_end - n_begin], db_row)
 struct GradRider {
     int job;               // index in the batch
@@ -407,13 +411,13 @@ bool grad_pair_takes_riders();
 hipError_t launch_grad_batch_with_rider(GradBatch& b, const GradRider& r, float* part, size_t part_floats, float* dbp,
                                         size_t dbp_floats, hipStream_t s);
 hipError_t launch_embed_train(const float* rays, int ray_ld, const float* z, int64_t P, int S, int Lx, int Lv,
-                              float* x0, int ld0, float* x1, int ld1, float* vcat, int ldv, int voff, hipStream_t s);
+                              float* x0, int ld0, float* x1, int ld1, float* vcat, int ldv, int voff, hipStream_t s, int pad = 0);
 hipError_t launch_mse(const float* x, const float* t, int64_t n, float* grad, double* part, float* loss, hipStream_t s);
 // The fused small launches of the training step (train_kernels.hip): each evaluates the expressions of the stage kernels it
 // replaces, through the same device functions (ray_device.h)
 hipError_t launch_train_prologue(const float* rays, int ray_ld, int64_t N, int S, int lindisp, const float* t_rand, float* z,
                                  int Lx, int Lv, float* x0, int ld0, float* x1, int ld1, float* vcat, int ldv, int voff,
-                                 unsigned* zero, int n_zero, hipStream_t s);
+                                 unsigned* zero, int n_zero, hipStream_t s, int pad = 0);
 hipError_t launch_train_mid(const float* raw, int C, const float* z_c, const float* rays_d, int d_ld, const float* noise,
                             int white_bkgd, int64_t N, int S, float* rgb_c, float* w_c, const float* u, int n_samples,
                             float* z_f, hipStream_t s);

@@ -204,7 +204,7 @@ size_t pass_floats(const PackedNet& net, int64_t P) {
     f += (size_t)P * 2 * (net.out_ch > 8 ? net.out_ch : 0);
     f += (size_t)P * a.W * 2 + (size_t)P * (a.W / 2);
     f += (size_t)(a.D + 1) * ((size_t)P * 8 + 64);    // Pass::mask, mask_hv
-    f += (size_t)(2 * a.D + 6) * 32 * (size_t)(a.W + 64);      // blocked buffers are whole groups of 32 points; gamma(x) apart
+    f += (size_t)(2 * a.D + 6) * 32 * (size_t)(a.W + 64) + (size_t)P * 72;      // blocked buffers are whole groups of 32 points; gamma(d) apart
     return f + 64 * 32;
 }
 
@@ -214,13 +214,15 @@ void carve_pass(Arena& ar, Pass& ps) {
     const int64_t P = ps.P;
     const size_t Pg = (size_t)((P + 31) / 32 * 32);      // whole groups of 32 points (blocked buffers)
     ps.C = net.out_ch;
-    float* E = ar.take((size_t)P * a.input_ch);
+    // gamma(x) for layer 0 (blocked passes: rows of 64, zero-padded - what the fp16-pipe gradients of those columns fetch)
+    const int e_ld = ps.blocked ? 64 : a.input_ch;
+    float* E = ar.take((size_t)P * e_ld);
     ps.in.assign(a.D, nullptr);
     ps.in_ld.assign(a.D, 0);
     ps.h.assign(a.D, nullptr);
     ps.h_ld.assign(a.D, 0);
     ps.in[0] = E;
-    ps.in_ld[0] = a.input_ch;
+    ps.in_ld[0] = e_ld;
     for (int i = 0; i < a.D; ++i) {
         const bool next_cat = (i + 1 < a.D) && ((net.skip_in_mask >> (i + 1)) & 1);
         if (ps.blocked) {
@@ -230,7 +232,7 @@ void carve_pass(Arena& ar, Pass& ps) {
             ps.h_ld[i] = a.W;
             if (next_cat) {      // (the same gamma(x) layer 0 reads: no second copy)
                 ps.in[i + 1] = E;
-                ps.in_ld[i + 1] = a.input_ch;
+                ps.in_ld[i + 1] = e_ld;
             } else if (i + 1 < a.D) {
                 ps.in[i + 1] = ps.h[i];
                 ps.in_ld[i + 1] = a.W;
@@ -257,7 +259,7 @@ void carve_pass(Arena& ar, Pass& ps) {
     if (a.use_viewdirs) {
         if (ps.blocked) {
             ps.feat_blk = ar.take(Pg * a.W);                              // the feature vector, blocked
-            ps.vcat_ld = (a.input_ch_views + 3) / 4 * 4;                  // gamma(dir) alone (nerf.py:93 concatenates them)
+            ps.vcat_ld = 64;                                              // gamma(dir) alone (nerf.py:93 concatenates them), zero-padded rows
             ps.vcat = ar.take((size_t)P * ps.vcat_ld);
             ps.voff = 0;
         } else {
@@ -362,10 +364,10 @@ hipError_t embed_inputs(Pass& ps, const float* rays, int ray_ld, float* z, int L
     hipError_t e = pro ? launch_train_prologue(rays, ray_ld, ps.N, ps.S, pro->lindisp, pro->t_rand, z, Lx, Lv, ps.in[0],
                                                ps.in_ld[0], first > 0 ? ps.in[first] : nullptr,
                                                first > 0 ? ps.in_ld[first] : 0, ps.vcat, ps.vcat_ld, ps.voff, pro->zero,
-                                               pro->n_zero, s)
+                                               pro->n_zero, s, ps.blocked ? 1 : 0)
                        : launch_embed_train(rays, ray_ld, z, ps.P, ps.S, Lx, Lv, ps.in[0], ps.in_ld[0],
                                             first > 0 ? ps.in[first] : nullptr, first > 0 ? ps.in_ld[first] : 0, ps.vcat,
-                                            ps.vcat_ld, ps.voff, s);
+                                            ps.vcat_ld, ps.voff, s, ps.blocked ? 1 : 0);
     for (int i = first + 1; first > 0 && i < a.D && e == hipSuccess; ++i)
         if ((net.skip_in_mask >> i) & 1)
             e = launch_embed_train(rays, ray_ld, z, ps.P, ps.S, Lx, 0, ps.in[i], ps.in_ld[i], nullptr, 0, nullptr, 0, 0, s);
@@ -630,7 +632,7 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     float* grad = net.train.d_grad;
     // (pairs: the jobs whose operands the backward kernel has measured - d z_i / d feature against the kept h_{i-1}, the
     // view layer's against a bound of the feature vector - go to the fp16-pair kernel when the context's arithmetic is F16X2)
-    GradBatch wide{}, narrow{}, pairs{};
+    GradBatch wide{}, narrow{}, pairs{}, narrow_pair{};
     // blocked: 0, or bit 0 = dY blocked by 32 points, bit 1 = X blocked with its feature 0 at column b_first (GradJob)
     auto job = [&](GradBatch& b, const LinearDesc& d, const float* dY, int ldy, const float* X, int ldx, int n0, int n1,
                    bool with_db, const unsigned* a_max = nullptr, const unsigned* b_max = nullptr, int blocked = 0,
@@ -645,18 +647,27 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     auto mx = [&](int slot) -> const unsigned* { return pair_dw ? ps.maxes + slot : nullptr; };
     if (ps.blocked) {
         // every hidden-width operand blocked by 32 points, in a buffer of its own; the gamma(x) / gamma(d) columns' jobs read
-        // a blocked dY against a narrow row-major X whose column 0 is column `first` of the Linear's input
+        // a blocked dY against a narrow row-major X (rows of 64, zero-padded) whose column 0 is column n_begin of the Linear's
+        // input: on the fp16 pipe too (grad_batch_narrow_pair_kernel), or - NERF_TRAIN_NARROW=f32 - on the fp32 one
+        static const bool narrow_pair_wanted = [] {
+            const char* e = getenv("NERF_TRAIN_NARROW");
+            return !(e && (e[0] == 'f' || e[0] == 'F') && e[1] == '3');
+        }();
+        GradBatch& nb = narrow_pair_wanted ? narrow_pair : narrow;
+        const int np = narrow_pair_wanted ? 1 : 0;
         job(pairs, feat, d_feat, a.W, ps.h[a.D - 1], a.W, 0, a.W, true, mx(kBwdMaxFeat), mx(kBwdMaxKept + a.D - 1), 3, 0);
         job(pairs, views, ps.g_hv, views.out, ps.feat_blk, a.W, 0, a.W, true, mx(kBwdMaxViews), mx(kBwdMaxFeatValue), 3, 0);
-        if (views.in > a.W) job(narrow, views, ps.g_hv, views.out, ps.vcat - a.W, ps.vcat_ld, a.W, views.in, false, nullptr, nullptr, 1);
+        if (views.in > a.W)
+            job(nb, views, ps.g_hv, views.out, np ? ps.vcat : ps.vcat - a.W, ps.vcat_ld, a.W, views.in, false, mx(kBwdMaxViews),
+                mx(kBwdMaxGammaD), 1);
         for (int i = a.D - 1; i >= 0; --i) {
             const LinearDesc& d = net.linears[i];
             if (d.in >= a.W) {
                 const int lead = d.in - a.W;                                           // cat[gamma(x), h] (nerf.py:79-80)
                 job(pairs, d, ps.dz[i], a.W, ps.h[i - 1], a.W, lead, d.in, true, mx(i), mx(kBwdMaxKept + i - 1), 3, lead);
-                if (lead > 0) job(narrow, d, ps.dz[i], a.W, ps.in[i], ps.in_ld[i], 0, lead, false, nullptr, nullptr, 1);
+                if (lead > 0) job(nb, d, ps.dz[i], a.W, ps.in[i], ps.in_ld[i], 0, lead, false, mx(i), mx(kBwdMaxGammaX), 1);
             } else {
-                job(narrow, d, ps.dz[i], a.W, ps.in[i], ps.in_ld[i], 0, d.in, true, nullptr, nullptr, 1);   // layer 0: gamma(x) only
+                job(nb, d, ps.dz[i], a.W, ps.in[i], ps.in_ld[i], 0, d.in, true, mx(i), mx(kBwdMaxGammaX), 1);   // layer 0: gamma(x) only
             }
         }
     } else {
@@ -696,6 +707,24 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
         } else {
             HIP_TRY(launch_grad_batch(*b, b != &narrow, sc.part, sc.part_floats, sc.dbp, sc.dbp_floats, s, b == &pairs));
         }
+    }
+    if (narrow_pair.n > 0) {
+        // a wave is a slice here, and a workgroup holds two (256-row jobs) or four (128-row jobs) of them: as many slices as fill
+        // the chip's 256 workgroups once over all jobs
+        double per_slice = 0.0;
+        for (int j = 0; j < narrow_pair.n; ++j) per_slice += narrow_pair.job[j].Mo > 128 ? 0.5 : 0.25;
+        int n_slices = (int)(256.0 / per_slice);
+        const int64_t cap = (ps.P + 255) / 256;
+        if (n_slices > cap) n_slices = (int)cap;
+        if (n_slices < 1) n_slices = 1;
+        int64_t pps = (ps.P + n_slices - 1) / n_slices;
+        pps = (pps + 31) / 32 * 32;
+        narrow_pair.n_slices = n_slices;
+        narrow_pair.pts_per_slice = pps;
+        narrow_pair.P = ps.P;
+        narrow_pair.accumulate = sc.accumulate;
+        TrainTimer timer(ps.ctx, s, 3, ps.P);
+        HIP_TRY(launch_grad_batch_narrow_pair(narrow_pair, sc.part, sc.part_floats, sc.dbp, sc.dbp_floats, s));
     }
     return NERF_OK;
 }

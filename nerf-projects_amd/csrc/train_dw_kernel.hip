@@ -569,6 +569,184 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The gamma(x) / gamma(d) columns' weight gradients on the fp16 pipe (blocked passes; round 4). dW[:, columns of the encoded
+// input] = dY^T gamma for layer 0, the skip layer and the view layer reads dY - a kilobyte per point - a second time for 63
+// (or 27) columns of X: on the fp32 matrix pipe (grad_batch_kernel<1>) that was 0.30 ms per iteration at 80 % of the pipe, and
+// 0.37 once dY was blocked (its register loads became 32-byte gathers). Here a WAVE is a slice: 128 rows x 64 columns (128
+// accumulators), dY through the padded LDS images of grad_batch_pair_dma_kernel<true> (eight coalesced KiB per 16-point
+// step), gamma - row-major [points, 64], zero-padded - as four more LDS-DMA KiB, two steps in flight, no barrier; per step 24
+// v_mfma_f32_32x32x16_f16 against 12 KiB of operands: the kernel is bound by reading dY once more, not by arithmetic. The waves of
+// a workgroup are 2 row halves x 2 slices (256 rows) or 4 slices (128 rows); slices are summed by grad_batch_reduce_kernel.
+// Arithmetic: the exact (hi, lo) split of both operands, one power-of-two scale per tensor (dY: the maxima the backward-data
+// kernel tracks; gamma(x): the range the forward kernel measures on its encoded inputs; gamma(d): 1), three products per term.
+// ---------------------------------------------------------------------------------------------
+constexpr int kNpSlots = 2;
+constexpr int kNpCols = 64;                                   // X columns per job (row stride of the gamma buffers)
+constexpr int kNpSlotBytes = 8 * kDmaImage + 16 * kNpCols * 4;   // a step's eight dY images + its [16 points][64 columns] of X
+constexpr size_t kNarrowPairLds = (size_t)4 * kNpSlots * kNpSlotBytes;
+
+template <int OFF>
+__device__ __forceinline__ void np_read32(float& v, unsigned addr) {
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int J>
+__device__ __forceinline__ void np_read_set(f32x4u (&a)[8], float (&x)[2][8], unsigned a_addr, unsigned x_addr) {
+    if constexpr (J < 8) {
+        dma_read<J * 32>(a[J], a_addr);
+        np_read32<8 * kDmaImage + J * kNpCols * 4>(x[0][J], x_addr);
+        np_read32<8 * kDmaImage + J * kNpCols * 4 + 128>(x[1][J], x_addr);
+        np_read_set<J + 1>(a, x, a_addr, x_addr);
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void grad_batch_narrow_pair_kernel(const GradBatch b) {
+    extern __shared__ __attribute__((aligned(16))) char np_ring[];
+    const GradJob& g = b.job[blockIdx.y];
+    const int width = g.n_end - g.n_begin;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), kh = lane >> 5, i = lane & 31;
+    const int wph = g.Mo > 128 ? 2 : 4;                    // waves (= slices) per row half
+    const int wm = wave / wph, ws = wave - wm * wph;
+    const int slice = blockIdx.x * wph + ws;
+    if (slice >= b.n_slices) return;                        // (no barrier anywhere below)
+    const int m_base = 128 * wm;
+    const int64_t p_begin = (int64_t)slice * b.pts_per_slice;
+    int64_t p_end = p_begin + b.pts_per_slice;
+    if (p_end > b.P) p_end = b.P;
+    const int64_t n_pts = p_end > p_begin ? p_end - p_begin : 0;
+    const int n_steps = (int)(n_pts / 16);
+
+    const int ea = pair_scale_exponent(g.a_max), eb = pair_scale_exponent(g.b_max);
+    const float sa = __builtin_ldexpf(1.0f, ea), sb = __builtin_ldexpf(1.0f, eb);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
+    float asum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    // dY blocked by 32 points: load j = piece j (lanes 0-31) and piece 8 + j (lanes 32-63) of this row half's sixteen, the
+    // 16-point half the step is in (grad_batch_pair_dma_kernel<true>); X: [16 points][64 floats] = four contiguous KiB
+    const float* pa = g.A + (p_begin >> 5) * (32 * (int64_t)g.Mo) + ((p_begin >> 4) & 1) * 128 + ((m_base >> 3) + 8 * kh) * 256 + 4 * i;
+    const float* px = g.B + p_begin * kNpCols + 4 * lane;
+    const int64_t group_a = 32 * (int64_t)g.Mo - 128;
+    int half = (int)((p_begin >> 4) & 1);
+    char* my = np_ring + (size_t)wave * kNpSlots * kNpSlotBytes;
+    const unsigned my_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)my;
+    const unsigned a_addr = my_lds + ((i >> 1) & 7) * kDmaImage + (i >> 4) * 512 + kh * 256 + (i & 1) * 16;
+    const unsigned x_addr = my_lds + kh * (8 * kNpCols * 4) + i * 4;      // points 8 kh .., column i (and 32 + i)
+
+    auto issue = [&](int slot) {
+        char* base = my + slot * kNpSlotBytes;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + j * 256),
+                                             (__attribute__((address_space(3))) void*)(base + j * kDmaImage), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(px + j * 256),
+                                             (__attribute__((address_space(3))) void*)(base + 8 * kDmaImage + j * 1024), 16, 0, 0);
+        pa += half ? group_a : 128;
+        half ^= 1;
+        px += 16 * kNpCols;
+    };
+    auto step = [&](const f32x4u (&ra)[8], const float (&rx)[2][8]) {
+        u32x4 ahi[4], alo[4], bhi[2], blo[2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float a0 = ra[2 * q][t], a1 = ra[2 * q + 1][t];
+                asum[t] += a0 + a1;
+                unsigned hi, lo;
+                pair_split(a0 * sa, a1 * sa, hi, lo);
+                ahi[t][q] = hi;
+                alo[t][q] = lo;
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                unsigned hi, lo;
+                pair_split(rx[c][2 * q] * sb, rx[c][2 * q + 1] * sb, hi, lo);
+                bhi[c][q] = hi;
+                blo[c][q] = lo;
+            }
+        }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                acc[tm][tn] = mfma16h(alo[tm], bhi[tn], acc[tm][tn]);
+                acc[tm][tn] = mfma16h(ahi[tm], blo[tn], acc[tm][tn]);
+                acc[tm][tn] = mfma16h(ahi[tm], bhi[tn], acc[tm][tn]);
+            }
+    };
+
+    for (int t = 0; t < kNpSlots && t < n_steps; ++t) issue(t);
+    int slot = 0;
+    for (int s = 0; s < n_steps; ++s) {
+        __builtin_amdgcn_sched_barrier(0);
+        // step s has landed when at most the twelve loads of the step issued after it are outstanding
+        if (s + 1 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        f32x4u ra[8];
+        float rx[2][8];
+        np_read_set<0>(ra, rx, a_addr + slot * kNpSlotBytes, x_addr + slot * kNpSlotBytes);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (read back: the slot may be overwritten)
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + kNpSlots < n_steps) issue(slot);
+        __builtin_amdgcn_sched_barrier(0);
+        step(ra, rx);
+        slot = slot + 1 == kNpSlots ? 0 : slot + 1;
+    }
+    // the tail: fewer than sixteen points, loads predicated per lane and point
+    const int64_t p_tail = p_begin + 16 * (int64_t)n_steps;
+    if (p_tail < p_end) {
+        f32x4u ra[8];
+        float rx[2][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t p = p_tail + 8 * kh + j;
+            const f32x4u z = {0.0f, 0.0f, 0.0f, 0.0f};
+            ra[j] = z;
+            rx[0][j] = rx[1][j] = 0.0f;
+            if (p < p_end) {
+                ra[j] = *(const f32x4u*)(g.A + (p >> 5) * (32 * (int64_t)g.Mo) + ((m_base + 4 * i) >> 3) * 256 + (int)(p & 31) * 8 + (i & 1) * 4);
+                rx[0][j] = g.B[p * kNpCols + i];
+                rx[1][j] = g.B[p * kNpCols + 32 + i];
+            }
+        }
+        step(ra, rx);
+    }
+
+    // acc[tm][tn][r] at lane (n = i, h = kh): row m_base + 4 (r&3 + 8 (r>>2) + 4 h) + tm, column 32 tn + n
+    const float descale = __builtin_ldexpf(1.0f, -(ea + eb));
+    float* part = g.part + (int64_t)slice * g.Mo * width;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int c = 32 * tn + i;
+        if (c < width) {
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m_base + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + tm;
+                    part[(int64_t)m * width + c] = acc[tm][tn][r] * descale;
+                }
+        }
+    }
+    if (g.db) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            const float t = asum[tm] + __shfl_xor(asum[tm], 32);
+            if (kh == 0) g.dbp[(int64_t)slice * g.Mo + m_base + 4 * i + tm] = t;
+        }
+    }
+}
+
 // part[s][m][c] summed over the slices in order (deterministic) into dW[m][n_begin + c]; thread = four consecutive elements
 // of one job (eight 16-byte loads in flight), the bias gradients behind them. A job whose operands were in the units of the
 // row-equalised network scales its sums by 2^(row_exp[m] - col_exp[n]) here (GradJob): the plain parameters' gradient.
@@ -631,6 +809,43 @@ static hipError_t launch_grad_batch_impl(GradBatch& b, bool wide, float* part, s
 hipError_t launch_grad_batch(GradBatch& b, bool wide, float* part, size_t part_floats, float* dbp, size_t dbp_floats,
                              hipStream_t s, bool pair) {
     return launch_grad_batch_impl(b, wide, part, part_floats, dbp, dbp_floats, s, pair, nullptr);
+}
+
+// the narrow jobs of a blocked pass on the fp16 pipe (grad_batch_narrow_pair_kernel): b.n_slices counts WAVE slices
+hipError_t launch_grad_batch_narrow_pair(GradBatch& b, float* part, size_t part_floats, float* dbp, size_t dbp_floats, hipStream_t s) {
+    if (b.n <= 0) return hipSuccess;
+    if (b.n > kMaxGradJobs || b.n_slices <= 0 || (b.pts_per_slice & 31)) return hipErrorInvalidValue;
+    size_t used = 0, used_db = 0;
+    int64_t max_threads = 0;
+    int max_blocks = 1;
+    for (int j = 0; j < b.n; ++j) {
+        GradJob& g = b.job[j];
+        const int width = g.n_end - g.n_begin;
+        if (g.Mo % 128 != 0 || g.Mo > 256 || width <= 0 || width > kNpCols || g.ldb != kNpCols || g.blocked != 1 || !g.a_max ||
+            !g.b_max || (reinterpret_cast<uintptr_t>(g.B) & 15))
+            return hipErrorInvalidValue;
+        g.part = part + used;
+        g.dbp = dbp + used_db;
+        used += (size_t)b.n_slices * g.Mo * width;
+        if (g.db) used_db += (size_t)b.n_slices * g.Mo;
+        const int64_t th = ((int64_t)g.Mo * width + 3) / 4 + g.Mo;
+        max_threads = th > max_threads ? th : max_threads;
+        const int wph = g.Mo > 128 ? 2 : 4, blocks = (b.n_slices + wph - 1) / wph;
+        max_blocks = blocks > max_blocks ? blocks : max_blocks;
+    }
+    if (used > part_floats || used_db > dbp_floats) return hipErrorInvalidValue;
+    static bool raised[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && !raised[dev]) {
+        e = hipFuncSetAttribute((const void*)grad_batch_narrow_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNarrowPairLds);
+        if (e != hipSuccess) return e;
+        raised[dev] = true;
+    }
+    hipLaunchKernelGGL(grad_batch_narrow_pair_kernel, dim3((unsigned)max_blocks, (unsigned)b.n), dim3(256), kNarrowPairLds, s, b);
+    hipLaunchKernelGGL(grad_batch_reduce_kernel, dim3((unsigned)((max_threads + 255) / 256), (unsigned)b.n), dim3(256), 0, s, b);
+    return hipGetLastError();
 }
 hipError_t launch_grad_batch_with_rider(GradBatch& b, const GradRider& r, float* part, size_t part_floats, float* dbp,
                                         size_t dbp_floats, hipStream_t s) {

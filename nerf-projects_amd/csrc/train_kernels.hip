@@ -646,6 +646,7 @@ struct EmbedPrologue {
     int lindisp;
     unsigned* zero;
     int n_zero;
+    int pad;                 // x0 and vcat rows are zero-padded to their strides
 };
 template <bool PROLOGUE>
 __global__ __launch_bounds__(256) void embed_train_kernel(const float* __restrict__ rays, int ray_ld, float* __restrict__ z,
@@ -706,36 +707,39 @@ __global__ __launch_bounds__(256) void embed_train_kernel(const float* __restric
         }
     __syncthreads();
     const int in_ch = 3 + 6 * Lx, in_v = 3 + 6 * Lv;
-    for (int it = threadIdx.x; it < n_here * in_ch; it += 256) {
-        const int pl = it / in_ch, col = it % in_ch;
-        const float v = sx[pl][col];
+    // (pro.pad: the rows of x0 and of vcat are padded with zeros to their strides - the fp16-pipe weight gradients of these
+    // columns fetch whole rows of 64, train_dw_kernel.hip grad_batch_narrow_pair_kernel)
+    const int w0 = pro.pad ? ld0 : in_ch, wv = pro.pad ? ldv - voff : in_v;
+    for (int it = threadIdx.x; it < n_here * w0; it += 256) {
+        const int pl = it / w0, col = it % w0;
+        const float v = col < in_ch ? sx[pl][col] : 0.0f;
         x0[(p0 + pl) * ld0 + col] = v;
-        if (x1) x1[(p0 + pl) * ld1 + col] = v;
+        if (x1 && col < in_ch) x1[(p0 + pl) * ld1 + col] = v;
     }
     if (vcat)
-        for (int it = threadIdx.x; it < n_here * in_v; it += 256) {
-            const int pl = it / in_v, col = it % in_v;
-            vcat[(p0 + pl) * ldv + voff + col] = sv[pl][col];
+        for (int it = threadIdx.x; it < n_here * wv; it += 256) {
+            const int pl = it / wv, col = it % wv;
+            vcat[(p0 + pl) * ldv + voff + col] = col < in_v ? sv[pl][col] : 0.0f;
         }
 }
 
 hipError_t launch_embed_train(const float* rays, int ray_ld, const float* z, int64_t P, int S, int Lx, int Lv,
-                              float* x0, int ld0, float* x1, int ld1, float* vcat, int ldv, int voff, hipStream_t s) {
+                              float* x0, int ld0, float* x1, int ld1, float* vcat, int ldv, int voff, hipStream_t s, int pad) {
     if (P <= 0) return hipSuccess;
     if (Lx < 0 || Lx > 10 || Lv < 0 || Lv > 4 || !x0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(embed_train_kernel<false>, dim3((unsigned)((P + kEmbedPoints - 1) / kEmbedPoints)), dim3(256), 0, s, rays,
-                       ray_ld, const_cast<float*>(z), P, S, Lx, Lv, x0, ld0, x1, ld1, vcat, ldv, voff, EmbedPrologue{});
+                       ray_ld, const_cast<float*>(z), P, S, Lx, Lv, x0, ld0, x1, ld1, vcat, ldv, voff, EmbedPrologue{nullptr, 0, nullptr, 0, pad});
     return hipGetLastError();
 }
 
 hipError_t launch_train_prologue(const float* rays, int ray_ld, int64_t N, int S, int lindisp, const float* t_rand, float* z,
                                  int Lx, int Lv, float* x0, int ld0, float* x1, int ld1, float* vcat, int ldv, int voff,
-                                 unsigned* zero, int n_zero, hipStream_t s) {
+                                 unsigned* zero, int n_zero, hipStream_t s, int pad) {
     const int64_t P = N * S;
     if (P <= 0) return hipSuccess;
     if (Lx < 0 || Lx > 10 || Lv < 0 || Lv > 4 || !x0 || !z) return hipErrorInvalidValue;
     hipLaunchKernelGGL(embed_train_kernel<true>, dim3((unsigned)((P + kEmbedPoints - 1) / kEmbedPoints)), dim3(256), 0, s, rays,
-                       ray_ld, z, P, S, Lx, Lv, x0, ld0, x1, ld1, vcat, ldv, voff, EmbedPrologue{t_rand, lindisp, zero, n_zero});
+                       ray_ld, z, P, S, Lx, Lv, x0, ld0, x1, ld1, vcat, ldv, voff, EmbedPrologue{t_rand, lindisp, zero, n_zero, pad});
     return hipGetLastError();
 }
 

@@ -1466,25 +1466,29 @@ np.savez(out_path, **res)
 """
 
 
-@pytest.mark.parametrize("n_imp,switch", [(128, "NERF_TRAIN_GLUE=legacy"), (0, "NERF_TRAIN_GLUE=legacy"), (128, "NERF_TRAIN_BLOCKED=0")])
+@pytest.mark.parametrize("n_imp,switch", [(128, "NERF_TRAIN_GLUE=legacy"), (0, "NERF_TRAIN_GLUE=legacy"),
+                                          (128, "NERF_TRAIN_NARROW=f32 NERF_TRAIN_BLOCKED=0")])
 def test_train_glue_is_bit_identical(N, n_imp, switch, tmp_path):
     """Two optimiser steps on the reference's fixture batch, twice: as shipped, and with one of the step's A/B switches thrown
     (each needs a process of its own: the switches are read once) - every loss, PSNR, colour, gradient and weight bit for bit.
     NERF_TRAIN_GLUE=legacy: the step's small stages as the stage kernels they were (stratified depths, encodings, raw2outputs,
     resampling, MSE, backward of raw2outputs; the refresh of the streams stage by stage) instead of the fused launches
     (prologue / mid / epilogue / two refresh launches). NERF_TRAIN_BLOCKED=0: the kept activations and pre-activation gradients
-    row-major instead of blocked by 32 points - the same values in the same registers of the same kernels."""
+    row-major instead of blocked by 32 points - the same values in the same registers of the same kernels (both runs with the
+    gamma columns' weight gradients on the fp32 pipe, NERF_TRAIN_NARROW=f32: their fp16-pipe kernel exists for the blocked
+    layout only)."""
     import subprocess
     import sys
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     precision = N.get_context().get_precision()
-    var, value = switch.split("=")
+    sets = [kv.split("=") for kv in switch.split()]      # the last one is the switch under test, the others hold in both runs
     results = {}
     for mode in ("shipped", "switched"):
         env = dict(os.environ)
-        env.pop(var, None)
-        if mode == "switched":
+        for var, value in sets:
+            env.pop(var, None)
+        for var, value in (sets if mode == "switched" else sets[:-1]):
             env[var] = value
         path = str(tmp_path / f"{mode}.npz")
         subprocess.run([sys.executable, "-c", _GLUE_RUN, root, path, precision, str(n_imp)], check=True, env=env, timeout=600)

@@ -82,3 +82,16 @@ def test_weight_gradient_kernel_prefetched_through_lds(tmp_path):
         assert "scratch_" not in body, inst
         assert body.count("global_load_lds_dwordx4") >= 32 and body.count("global_load_lds_dword ") >= 1, inst
         assert set(re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)) == {"0", "16", "17"}, inst
+    # the gamma columns' kernel: eight dY images + four KiB of X per step, twelve loads a step
+    inst = "grad_batch_narrow_pair_kernel"
+    findings, n_ops, n_waits = audit.audit(str(out), inst)
+    assert n_ops > 20 and n_waits > 1, (inst, n_ops, n_waits)
+    assert not findings, (inst, findings[:5])
+    assert not audit.audit_sgpr_hazards(str(out), inst), inst
+    body = text[text.index(inst):]
+    body = body[:body.index("s_endpgm")]
+    assert "scratch_" not in body, inst
+    assert body.count("global_load_lds_dwordx4") >= 12, inst
+    # (the tail's predicated register loads bring hipcc's own small counts; the loop's wait is the one the source states)
+    waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)
+    assert waits.count("12") == 1 and "0" in waits and all(int(w) <= 12 for w in waits), (inst, waits)
