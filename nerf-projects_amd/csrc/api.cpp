@@ -213,7 +213,7 @@ void free_net(PackedNet& n) {
                     (void*)n.train.d_v, (void*)n.train.d_wt, (void*)n.train.d_stream_table,
                     (void*)n.train.d_bias_table, (void*)n.train.d_bwd_table, (void*)n.train.d_stream_bwd, (void*)n.d_stream_h2, (void*)n.d_descale, (void*)n.d_chunk_layer,
                     (void*)n.d_chunk_max, (void*)n.d_gain, (void*)n.d_params_eq, (void*)n.d_stream_eq, (void*)n.d_bias_h2,
-                    (void*)n.d_row_exp, (void*)n.train.d_stream_bwd_h2, (void*)n.train.d_descale_bwd, (void*)n.train.d_gain_bwd,
+                    (void*)n.d_row_exp, (void*)n.d_eq_flags, (void*)n.train.d_stream_bwd_h2, (void*)n.train.d_descale_bwd, (void*)n.train.d_gain_bwd,
                     (void*)n.train.d_chunk_layer_bwd, (void*)n.train.d_chunk_max_bwd})
         if (p) (void)hipFree(p);
     n = PackedNet{};

@@ -107,6 +107,9 @@ struct PackedNet {
     // e_j of every hidden unit ([kMaxLinears][256], 0 where rows are not scaled), chosen by every refresh_h2: the training step
     // turns the equalised network's gradients into the plain parameters' with them (GradJob::ex)
     int* d_row_exp = nullptr;
+    // row_exponents_layers_kernel (one workgroup per linear): flag k = the launch's epoch once linear k's exponents are written
+    unsigned* d_eq_flags = nullptr;
+    unsigned eq_epoch = 0;
     int n_chunks = 0;
     int n_bias_tiles = 0;
     uint32_t skip_in_mask = 0;   // bit i: trunk layer i reads [input_pts, h]
@@ -261,7 +264,7 @@ struct EqualiseRefs {
 // row_exp [kMaxLinears][256]: e_j of every linear (0 where rows are not scaled): chosen, written out and applied - for one
 // network or two in the same pair of launches (the training step equalises the coarse and the fine network together)
 hipError_t launch_equalise_rows(int n, const float* const* params, const EqualiseRefs* refs, float* const* params_eq,
-                                int* const* row_exp, hipStream_t s);
+                                int* const* row_exp, hipStream_t s, unsigned* const* flags = nullptr, unsigned epoch = 0);
 EqualiseRefs equalise_refs(const nerf_arch& arch, const std::vector<LinearDesc>& linears);
 struct PackedNet;
 // everything the fp16-pair kernel reads, rebuilt from the master parameters (api.cpp; at load and, lazily, after training steps)

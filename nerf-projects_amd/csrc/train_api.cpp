@@ -130,7 +130,22 @@ int refresh_after_step(nerf_ctx* c, PackedNet* const* nets, int n, hipStream_t s
         rexp[i] = nets[i]->d_row_exp;
         refs[i] = equalise_refs(nets[i]->arch, nets[i]->linears);
     }
-    HIP_TRY(launch_equalise_rows(n, params, refs, out, rexp, s));
+    unsigned* flags[2] = {nullptr, nullptr};
+    for (int i = 0; i < n; ++i) {
+        PackedNet& net = *nets[i];
+        if (!net.d_eq_flags) {
+            HIP_TRY(hipMalloc((void**)&net.d_eq_flags, kMaxLinears * sizeof(unsigned)));
+            HIP_TRY(hipMemsetAsync(net.d_eq_flags, 0, kMaxLinears * sizeof(unsigned), s));
+            net.eq_epoch = 0;
+        }
+        flags[i] = net.d_eq_flags;
+    }
+    // (one epoch for the launch: both networks' counters move together; 0 is the value of a fresh flag and is skipped)
+    unsigned epoch = nets[0]->eq_epoch + 1;
+    if (n > 1 && nets[1]->eq_epoch + 1 > epoch) epoch = nets[1]->eq_epoch + 1;
+    if (epoch == 0) epoch = 1;
+    for (int i = 0; i < n; ++i) nets[i]->eq_epoch = epoch;
+    HIP_TRY(launch_equalise_rows(n, params, refs, out, rexp, s, flags, epoch));
     RefreshBatch b{};
     for (int i = 0; i < n; ++i) {
         PackedNet& net = *nets[i];
@@ -709,16 +724,14 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
         }
     }
     if (narrow_pair.n > 0) {
-        // a wave is a slice here, and a workgroup holds two (256-row jobs) or four (128-row jobs) of them: as many slices as fill
-        // the chip's 256 workgroups once over all jobs
-        double per_slice = 0.0;
-        for (int j = 0; j < narrow_pair.n; ++j) per_slice += narrow_pair.job[j].Mo > 128 ? 0.5 : 0.25;
-        int n_slices = (int)(256.0 / per_slice);
+        // a workgroup is a slice (its four waves share its points and add their sums up in LDS): as many as fill the chip's 256
+        // workgroups once over all jobs
+        int n_slices = 256 / narrow_pair.n;
         const int64_t cap = (ps.P + 255) / 256;
         if (n_slices > cap) n_slices = (int)cap;
         if (n_slices < 1) n_slices = 1;
         int64_t pps = (ps.P + n_slices - 1) / n_slices;
-        pps = (pps + 31) / 32 * 32;
+        pps = (pps + 127) / 128 * 128;
         narrow_pair.n_slices = n_slices;
         narrow_pair.pts_per_slice = pps;
         narrow_pair.P = ps.P;

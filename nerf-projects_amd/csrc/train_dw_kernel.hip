@@ -343,6 +343,11 @@ void grad_batch_pair_kernel(const GradBatch b) {
 // image j starts at j x (1024 + 32): the eight pieces j of a group then differ by 32 bytes modulo the 256-byte bank row, the
 // two half-waves h by 16 (SQ_LDS_BANK_CONFLICT stays 0). Same loads per step, same bytes in flight, same registers after the
 // read-back as the row-major form - only the addresses differ.
+#ifdef NERF_EXP_DW_NT      // timing experiment: the operands' LDS-DMA loads with the nt bit (they are read once)
+constexpr int kDmaAux = 2;
+#else
+constexpr int kDmaAux = 0;
+#endif
 constexpr int kDmaSlots = 2;
 constexpr int kDmaImage = 1024 + 32;           // one load instruction's KiB in LDS (BLK: padded, see above)
 constexpr int kDmaRiderOff = 16 * kDmaImage;   // behind a step's sixteen images: its sixteen y values (GradJob::y), one 256-byte load
@@ -425,9 +430,9 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + j * load_a),
-                                             (__attribute__((address_space(3))) void*)(base + j * kDmaImage), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + j * kDmaImage), 16, 0, kDmaAux);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + j * load_b),
-                                             (__attribute__((address_space(3))) void*)(base + 8 * kDmaImage + j * kDmaImage), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + 8 * kDmaImage + j * kDmaImage), 16, 0, kDmaAux);
         }
         if (has_y) {      // lane l fetches y of point (l & 15) of the step: LDS [16 floats] x 4 copies
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)py,
@@ -606,13 +611,14 @@ void grad_batch_narrow_pair_kernel(const GradBatch b) {
     const GradJob& g = b.job[blockIdx.y];
     const int width = g.n_end - g.n_begin;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), kh = lane >> 5, i = lane & 31;
-    const int wph = g.Mo > 128 ? 2 : 4;                    // waves (= slices) per row half
+    const int wph = g.Mo > 128 ? 2 : 4;                    // waves per row half: each takes a share of the workgroup's points
     const int wm = wave / wph, ws = wave - wm * wph;
-    const int slice = blockIdx.x * wph + ws;
-    if (slice >= b.n_slices) return;                        // (no barrier anywhere below)
+    const int slice = blockIdx.x;                           // a workgroup is a slice; its waves' sums are added up in LDS at the end
+    if (slice >= b.n_slices) return;                        // (uniform over the workgroup)
     const int m_base = 128 * wm;
-    const int64_t p_begin = (int64_t)slice * b.pts_per_slice;
-    int64_t p_end = p_begin + b.pts_per_slice;
+    const int64_t sub = b.pts_per_slice / wph;              // (a multiple of 32: launch_grad_batch_narrow_pair)
+    const int64_t p_begin = (int64_t)slice * b.pts_per_slice + ws * sub;
+    int64_t p_end = p_begin + sub;
     if (p_end > b.P) p_end = b.P;
     const int64_t n_pts = p_end > p_begin ? p_end - p_begin : 0;
     const int n_steps = (int)(n_pts / 16);
@@ -722,6 +728,37 @@ void grad_batch_narrow_pair_kernel(const GradBatch b) {
         step(ra, rx);
     }
 
+    // ---- the waves of a row half add their sums up (a partial per workgroup, not per wave: the pass over the partials is
+    //      latency-bound on their number): the upper half of them hands its registers over through the ring's memory, twice
+    //      for four waves. Fixed order, so the result does not depend on timing. ----
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    for (int span = wph >> 1; span >= 1; span >>= 1) {
+        __syncthreads();
+        float* box = (float*)np_ring + (size_t)(wm * (wph >> 1) + (ws - span)) * (132 * 64);      // 128 sums + 4 bias sums per lane
+        if (ws >= span && ws < 2 * span) {
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) box[((tm * 2 + tn) * 16 + r) * 64 + lane] = acc[tm][tn][r];
+                box[(128 + tm) * 64 + lane] = asum[tm];
+            }
+        }
+        __syncthreads();
+        if (ws < span) {
+            const float* from = (const float*)np_ring + (size_t)(wm * (wph >> 1) + ws) * (132 * 64);
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tm][tn][r] += from[((tm * 2 + tn) * 16 + r) * 64 + lane];
+                asum[tm] += from[(128 + tm) * 64 + lane];
+            }
+        }
+    }
+    if (ws != 0) return;
     // acc[tm][tn][r] at lane (n = i, h = kh): row m_base + 4 (r&3 + 8 (r>>2) + 4 h) + tm, column 32 tn + n
     const float descale = __builtin_ldexpf(1.0f, -(ea + eb));
     float* part = g.part + (int64_t)slice * g.Mo * width;
@@ -811,10 +848,10 @@ hipError_t launch_grad_batch(GradBatch& b, bool wide, float* part, size_t part_f
     return launch_grad_batch_impl(b, wide, part, part_floats, dbp, dbp_floats, s, pair, nullptr);
 }
 
-// the narrow jobs of a blocked pass on the fp16 pipe (grad_batch_narrow_pair_kernel): b.n_slices counts WAVE slices
+// the narrow jobs of a blocked pass on the fp16 pipe (grad_batch_narrow_pair_kernel): a workgroup is a slice
 hipError_t launch_grad_batch_narrow_pair(GradBatch& b, float* part, size_t part_floats, float* dbp, size_t dbp_floats, hipStream_t s) {
     if (b.n <= 0) return hipSuccess;
-    if (b.n > kMaxGradJobs || b.n_slices <= 0 || (b.pts_per_slice & 31)) return hipErrorInvalidValue;
+    if (b.n > kMaxGradJobs || b.n_slices <= 0 || (b.pts_per_slice & 127)) return hipErrorInvalidValue;      // (four shares of whole groups of 32)
     size_t used = 0, used_db = 0;
     int64_t max_threads = 0;
     int max_blocks = 1;
@@ -830,8 +867,7 @@ hipError_t launch_grad_batch_narrow_pair(GradBatch& b, float* part, size_t part_
         if (g.db) used_db += (size_t)b.n_slices * g.Mo;
         const int64_t th = ((int64_t)g.Mo * width + 3) / 4 + g.Mo;
         max_threads = th > max_threads ? th : max_threads;
-        const int wph = g.Mo > 128 ? 2 : 4, blocks = (b.n_slices + wph - 1) / wph;
-        max_blocks = blocks > max_blocks ? blocks : max_blocks;
+        max_blocks = b.n_slices;
     }
     if (used > part_floats || used_db > dbp_floats) return hipErrorInvalidValue;
     static bool raised[64] = {};
