@@ -343,11 +343,7 @@ void grad_batch_pair_kernel(const GradBatch b) {
 // image j starts at j x (1024 + 32): the eight pieces j of a group then differ by 32 bytes modulo the 256-byte bank row, the
 // two half-waves h by 16 (SQ_LDS_BANK_CONFLICT stays 0). Same loads per step, same bytes in flight, same registers after the
 // read-back as the row-major form - only the addresses differ.
-#ifdef NERF_EXP_DW_NT      // timing experiment: the operands' LDS-DMA loads with the nt bit (they are read once)
-constexpr int kDmaAux = 2;
-#else
-constexpr int kDmaAux = 0;
-#endif
+// (the operands' loads with the nt bit - they are read once - measured no faster: 299.9 against 301.1 it/s, profiles/r04_ab_notes.txt)
 constexpr int kDmaSlots = 2;
 constexpr int kDmaImage = 1024 + 32;           // one load instruction's KiB in LDS (BLK: padded, see above)
 constexpr int kDmaRiderOff = 16 * kDmaImage;   // behind a step's sixteen images: its sixteen y values (GradJob::y), one 256-byte load
@@ -430,9 +426,9 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + j * load_a),
-                                             (__attribute__((address_space(3))) void*)(base + j * kDmaImage), 16, 0, kDmaAux);
+                                             (__attribute__((address_space(3))) void*)(base + j * kDmaImage), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + j * load_b),
-                                             (__attribute__((address_space(3))) void*)(base + 8 * kDmaImage + j * kDmaImage), 16, 0, kDmaAux);
+                                             (__attribute__((address_space(3))) void*)(base + 8 * kDmaImage + j * kDmaImage), 16, 0, 0);
         }
         if (has_y) {      // lane l fetches y of point (l & 15) of the step: LDS [16 floats] x 4 copies
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)py,
