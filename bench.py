@@ -335,17 +335,41 @@ def train_leg(N, synthetic, iters=30, warmup=5, n_rand=1024, Sc=64, Si=128):
         kernels[name] = k
     ms_o, _, _ = spans["weight_gradients_other"]
     kernels["weight_gradients_other"] = {"ms_per_iter": ms_o / n_prof, "pipe": "f32"}
+    # networks without view directions (use_viewdirs=False: output_linear on the trunk, nerf.ipynb:885-896): the same loop body,
+    # short (since round 4 on the same three fp16-pair kernels, output_linear as one more chunk in both directions)
+    nv = dict(D=8, W=256, input_ch=63, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False)
+    nv_c, nv_f = (N.NeRF(**nv).load_state_dict(synthetic.synthetic_state_dict(s_, input_ch_views=0, use_viewdirs=False, output_ch=5))
+                  for s_ in (8, 48))
+    nv_opt = N.Adam([nv_c, nv_f], lr=5e-4, betas=(0.9, 0.999))
+    nv_kw = dict(kw, network_fn=nv_c, network_fine=nv_f, use_viewdirs=False)
+
+    def one_nv(i):
+        idx = state["perm"][(i * n_rand) % (packed.shape[0] - n_rand):][:n_rand]
+        r = packed[idx]
+        return N.train_on_batch(800, 800, K, (r[:, 0:3], r[:, 3:6]), torch.rand((n_rand, 3), device="cuda"), nv_opt, **nv_kw)
+
+    for i in range(warmup):
+        one_nv(i)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    n_nv = 20
+    for i in range(n_nv):
+        one_nv(i)
+    torch.cuda.synchronize()
+    noviewdirs = {"value": n_nv / (time.perf_counter() - t1), "unit": "it/s", "iters": n_nv,
+                  "model": "use_viewdirs=False, output_ch=5 (create_nerf's other branch)"}
     evals = n_rand * (Sc + Sc + Si)
     tf = evals * FLOP_PER_EVAL * 3 * iters / dt / 1e12          # forward + dX + dW
     return {"metric": "train_iterations_per_sec", "value": iters / dt, "unit": "it/s", "iters": iters,
             "ms_per_iter": dt / iters * 1e3, "n_rand": n_rand, "N_samples": Sc, "N_importance": Si,
-            "tflops_effective": tf, "kernels": kernels,
-            "arithmetic": ("forward, backward-data and the hidden-width weight gradients: fp16-pair kernels on the row-equalised "
-                           "network (3 x v_mfma_f32_32x32x16_f16 per term, fp32 accumulate, fp32-level error); "
+            "tflops_effective": tf, "kernels": kernels, "train_noviewdirs": noviewdirs,
+            "arithmetic": ("forward, backward-data and the weight gradients of every Linear but rgb_linear: fp16-pair kernels on the "
+                           "row-equalised network (3 x v_mfma_f32_32x32x16_f16 per term, fp32 accumulate, fp32-level error), kept "
+                           "activations blocked by 32 points; "
                            if (pair_forward and pair_bwd and pair_dw) else
                            f"forward: {'fp16-pair' if pair_forward else 'f32'}; backward-data: {'fp16-pair' if pair_bwd else 'f32'}; "
                            f"hidden-width weight gradients: {'fp16-pair' if pair_dw else 'f32'}; ") +
-                          "other weight gradients, compositing, Adam: f32, fp32 master weights",
+                          "rgb_linear's weight gradient, compositing, Adam: f32, fp32 master weights",
             "batches": "use_batching windows of one shuffle (nerf.ipynb:1209-1230)",
             "final_loss": float(out["loss"]),
             "reference_stored_run": "5.6-7.4 it/s (ship 96+192, unknown CUDA GPU; BASELINE.md section 1)"}

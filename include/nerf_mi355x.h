@@ -371,6 +371,11 @@ typedef struct nerf_train_args {
     float* rgb_map;             /* [dev] [N,3] optional                                         */
     float* rgb0;                /* [dev] [N,3] optional                                         */
     void* stream;
+    const float* z_vals_fine_in;/* [dev] [N,S_c+S_i] optional: the fine pass at THESE depths instead of the resampled ones (the
+                                   resampling still runs; parity tests inject the reference's fine depths, as
+                                   nerf_render_args::z_vals_fine_in does for rendering: sample_pdf is ill-conditioned where a
+                                   bin's mass is tiny, and a depth that moves by 5e-4 turns the top-frequency columns of
+                                   gamma(x) - hence layer 0's weight gradient - by a third of a radian)            */
     float* stats;               /* [dev] [5] optional: img_loss, img_loss0, loss = their sum, psnr = mse2psnr(img_loss), psnr0
                                    (nerf.ipynb:1262-1272, nerf_helpers.py:14) - what the loop body prints, without a tensor
                                    operation per number (entries 1 and 4 are 0 when N_importance = 0)            */

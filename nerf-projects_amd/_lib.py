@@ -54,7 +54,7 @@ class TrainArgs(C.Structure):
                 ("t_rand", _FP), ("u_rand", _FP), ("noise0", _FP), ("noise", _FP), ("lr", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int32),
                 ("apply_update", C.c_int32), ("loss", _FP), ("rgb_map", _FP), ("rgb0", _FP), ("stream", C.c_void_p),
-                ("stats", _FP)]
+                ("z_vals_fine_in", _FP), ("stats", _FP)]
 
 
 class Camera(C.Structure):

@@ -114,7 +114,12 @@ __device__ __forceinline__ void bconvert_tile(XT& dst, const f32x16& src, Pendin
 constexpr int kPreSlotBytes = 1024;      // one 16-byte record per lane
 constexpr int kRgbRowFloats = 12 * kBiasTileFloats;
 
-template <bool BLK>
+// VIEWS = false: networks without view directions (output_linear on the trunk, nerf.py:109; round 4). The chain starts at
+// d h_{D-1} = W_output^T d raw: ONE chunk - the head's C <= 8 rows as columns 0..C-1 of a k-tile, d raw as the operand (each
+// half-wave holds four channels: d raw is [P, 8], zero-padded) - where the view-dependent chain spends thirteen on the view
+// layer, feature_linear and the alpha column. Slots of the per-wave records: [0] d raw and [1] the mask of trunk layer D-1, both
+// a tile ahead.
+template <bool BLK, bool VIEWS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
     extern __shared__ __attribute__((aligned(16))) char ring_lds[];
@@ -139,7 +144,8 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
     }
     prefetch_pieces<0, 4>(piece_src(pipe, 2), piece_dst(pipe, 2));   // chunk 0's first-half steps issue the other four
     // rgb_linear's rows: bias-block tiles 8D+22 .. 8D+33 (pack_weights.cpp row_tiles)
-    for (int i = threadIdx.x; i < kRgbRowFloats; i += 256) rgb_lds[i] = b.bias[(8 * D + 22) * kBiasTileFloats + i];
+    if constexpr (VIEWS)
+        for (int i = threadIdx.x; i < kRgbRowFloats; i += 256) rgb_lds[i] = b.bias[(8 * D + 22) * kBiasTileFloats + i];
     if (threadIdx.x < kBwdMaxSlots) max_record[threadIdx.x] = 0u;
     if (threadIdx.x < kLooseRecord) loose_hist[threadIdx.x] = 0u;
     if ((int)threadIdx.x <= D) {
@@ -161,10 +167,13 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
     };
     auto fetched = [&](int slot) { return (const float*)(my_pre + slot * kPreSlotBytes + lane * 16); };
     auto mask_rec = [&](const unsigned* base, int64_t pt) { return base + 4 * (2 * pt + h); };
+    // this lane's 16 bytes of d raw: the point's four channels (VIEWS), or the four of this half-wave out of eight
+    auto d_raw_rec = [&](int64_t pt) { return VIEWS ? b.d_raw + pt * 4 : b.d_raw + pt * 8 + 4 * h; };
+    auto first_mask = [&](int64_t pt) { return VIEWS ? mask_rec(b.fwd.mask_hv, pt) : mask_rec(b.fwd.mask[D - 1], pt); };
     if ((int64_t)blockIdx.x < n_tiles) {
         const int64_t pt0 = point_of(blockIdx.x);
-        fetch(b.d_raw + pt0 * 4, 0);
-        fetch(mask_rec(b.fwd.mask_hv, pt0), 1);
+        fetch(d_raw_rec(pt0), 0);
+        fetch(first_mask(pt0), 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // chunks 0, 1, the rgb rows, the layer table and the first tile's records are in LDS
@@ -188,59 +197,72 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
         PendingB pd;
         float m_prev, dsig_abs, dsig_h0;
 
+        f32x4 dr_head = {0.0f, 0.0f, 0.0f, 0.0f};      // (!VIEWS) this half-wave's four channels of d raw
+        int t_head = 0;
+        if constexpr (VIEWS) {
         // ---- d(view pre-activation) = (d rgb . W_rgb) * [hv > 0], in the open (nerf.py:101, :96-98) ----
-        {
-            const f32x4 dr = lds_vec4(fetched(0));
-            const f32x4 mh = lds_vec4(fetched(1));
-            const unsigned mw[2] = {__float_as_uint(mh[0]), __float_as_uint(mh[1])};
-            dsig_abs = fabsf(dr[3]);
-            dsig_h0 = h == 0 ? dr[3] : 0.0f;
-            f32x16 g[4];
-            float m = 0.0f;
-            // (blocked: 16 KiB per point group of this 128-wide buffer)
-            const unsigned off = BLK ? ((unsigned)pt >> 5) * 16384u + ((unsigned)pt & 31u) * 32u + (unsigned)h * 16u
-                                     : 4u * ((unsigned)pt * (unsigned)b.out.hv_ld + 4u * (unsigned)h);
-            Tile16 w0 = lds_tile_issue(rgb0), w1 = lds_tile_issue(rgb0 + 128 * 4), w2 = lds_tile_issue(rgb0 + 128 * 8);
+            {
+                const f32x4 dr = lds_vec4(fetched(0));
+                const f32x4 mh = lds_vec4(fetched(1));
+                const unsigned mw[2] = {__float_as_uint(mh[0]), __float_as_uint(mh[1])};
+                dsig_abs = fabsf(dr[3]);
+                dsig_h0 = h == 0 ? dr[3] : 0.0f;
+                f32x16 g[4];
+                float m = 0.0f;
+                // (blocked: 16 KiB per point group of this 128-wide buffer)
+                const unsigned off = BLK ? ((unsigned)pt >> 5) * 16384u + ((unsigned)pt & 31u) * 32u + (unsigned)h * 16u
+                                         : 4u * ((unsigned)pt * (unsigned)b.out.hv_ld + 4u * (unsigned)h);
+                Tile16 w0 = lds_tile_issue(rgb0), w1 = lds_tile_issue(rgb0 + 128 * 4), w2 = lds_tile_issue(rgb0 + 128 * 8);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                lds_tile_wait(w0);
-                lds_tile_wait(w1);
-                lds_tile_wait(w2);
+                for (int t = 0; t < 4; ++t) {
+                    lds_tile_wait(w0);
+                    lds_tile_wait(w1);
+                    lds_tile_wait(w2);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = fmaf(dr[2], w2.q[r >> 2][r & 3], fmaf(dr[1], w1.q[r >> 2][r & 3], dr[0] * w0.q[r >> 2][r & 3]));
-                    // value r = 2s (+1) of tile t: bit 15 (31) - 8 (t & 1) - s of word t / 2
-                    const int bit = ((r & 1) ? 31 : 15) - 8 * (t & 1) - (r >> 1);
-                    g[t][r] = ((mw[t >> 1] >> bit) & 1u) ? v : 0.0f;
-                    m = fmaxf(m, fabsf(g[t][r]));
-                }
-                if (t + 1 < 4) {
-                    w0 = lds_tile_issue(rgb0 + 128 * (t + 1));
-                    w1 = lds_tile_issue(rgb0 + 128 * (4 + t + 1));
-                    w2 = lds_tile_issue(rgb0 + 128 * (8 + t + 1));
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = fmaf(dr[2], w2.q[r >> 2][r & 3], fmaf(dr[1], w1.q[r >> 2][r & 3], dr[0] * w0.q[r >> 2][r & 3]));
+                        // value r = 2s (+1) of tile t: bit 15 (31) - 8 (t & 1) - s of word t / 2
+                        const int bit = ((r & 1) ? 31 : 15) - 8 * (t & 1) - (r >> 1);
+                        g[t][r] = ((mw[t >> 1] >> bit) & 1u) ? v : 0.0f;
+                        m = fmaxf(m, fabsf(g[t][r]));
+                    }
+                    if (t + 1 < 4) {
+                        w0 = lds_tile_issue(rgb0 + 128 * (t + 1));
+                        w1 = lds_tile_issue(rgb0 + 128 * (4 + t + 1));
+                        w2 = lds_tile_issue(rgb0 + 128 * (8 + t + 1));
+                    }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = {g[t][4 * q], g[t][4 * q + 1], g[t][4 * q + 2], g[t][4 * q + 3]};
-                    if constexpr (BLK)
-                        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1"
-                                     :
-                                     : "v"(off + (unsigned)((4 * t + q) * 1024)), "v"(v), "s"(b.out.hv)
-                                     : "memory");
-                    else
-                        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1"
-                                     :
-                                     : "v"(off + (unsigned)((32 * t + 8 * q) * 4)), "v"(v), "s"(b.out.hv)
-                                     : "memory");
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {g[t][4 * q], g[t][4 * q + 1], g[t][4 * q + 2], g[t][4 * q + 3]};
+                        if constexpr (BLK)
+                            asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1"
+                                         :
+                                         : "v"(off + (unsigned)((4 * t + q) * 1024)), "v"(v), "s"(b.out.hv)
+                                         : "memory");
+                        else
+                            asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1"
+                                         :
+                                         : "v"(off + (unsigned)((32 * t + 8 * q) * 4)), "v"(v), "s"(b.out.hv)
+                                         : "memory");
+                    }
                 }
+                m_prev = half_max(m);
+                enter_max(&max_record[kBwdMaxViews], m_prev);
+                const int t_v = pick_exponent(m_prev);
+                const float sc = pow2f(t_v);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) split_tile(hid[t], g[t], sc);
+                pd.t_out = t_v;
             }
-            m_prev = half_max(m);
-            enter_max(&max_record[kBwdMaxViews], m_prev);
-            const int t_v = pick_exponent(m_prev);
-            const float sc = pow2f(t_v);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) split_tile(hid[t], g[t], sc);
-            pd.t_out = t_v;
+
+        } else {
+            // ---- the operand of the head's chunk: d raw at its own per-point scale ----
+            dr_head = lds_vec4(fetched(0));
+            dsig_abs = 0.0f;
+            dsig_h0 = 0.0f;
+            m_prev = half_max(fmaxf(fmaxf(fabsf(dr_head[0]), fabsf(dr_head[1])), fmaxf(fabsf(dr_head[2]), fabsf(dr_head[3]))));
+            t_head = pick_exponent(m_prev);
+            pd.t_out = t_head;
         }
 
         // what the raw sums of backward layer bl become: called when its chunks are done. m_in = largest |input| of the layer
@@ -248,9 +270,12 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
         auto make_pending = [&](int bl_, float m_in, int t_in) {
             const int bl = __builtin_amdgcn_readfirstlane(bl_);
             f32x4 tab, mk;
+            // (the mask of the layer these sums belong to: requested when its chunks began - slot 2 - or, for the no-views chain's
+            // first layer, a tile ahead - slot 1)
+            const float* mask_at = (!VIEWS && bl == 1) ? fetched(1) : fetched(2);
             asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                          : "=&v"(tab), "=&v"(mk)
-                         : "v"(lds_byte_addr(layer_tab + 4 * bl)), "v"(lds_byte_addr(fetched(2)))
+                         : "v"(lds_byte_addr(layer_tab + 4 * bl)), "v"(lds_byte_addr(mask_at))
                          : "memory");
             pd.c = tab[0] * pow2f(-t_in);
             float bound = tab[1] * m_in;
@@ -292,19 +317,32 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
             if (slot >= 0) enter_max(&max_record[slot], m_prev);
         };
 
-        // ---- d feature = W_views[:, :W]^T d(view pre-activation): four k-tiles, nothing pending yet ----
-        chunk_bwd<-1, true, BLK>(pipe, cur, accA, hid[0], hid, accB, pd);
-        chunk_bwd<-1, false, BLK>(pipe, cur, accA, hid[1], hid, accB, pd);
-        chunk_bwd<-1, false, BLK>(pipe, cur, accA, hid[2], hid, accB, pd);
-        chunk_bwd<-1, false, BLK>(pipe, cur, accA, hid[3], hid, accB, pd);
-        make_pending(0, m_prev, pd.t_out);
-        // the alpha column's operand: d sigma as value 0 of half-wave 0 (the column k = 0 of its k-tile), at d feature's scale
-        XT xs;
-        xs.hi[0] = u32x4{0u, 0u, 0u, 0u};
-        xs.hi[1] = xs.hi[0];
-        xs.lo[0] = xs.hi[0];
-        xs.lo[1] = xs.hi[0];
-        split_pair<0>(xs, dsig_h0 * pd.sc, 0.0f);
+        XT xs;      // (filled where it is first needed: sixteen registers the four chunks before it cannot spare)
+        auto clear_xs = [&]() {
+            xs.hi[0] = u32x4{0u, 0u, 0u, 0u};
+            xs.hi[1] = xs.hi[0];
+            xs.lo[0] = xs.hi[0];
+            xs.lo[1] = xs.hi[0];
+        };
+        if constexpr (VIEWS) {
+            // ---- d feature = W_views[:, :W]^T d(view pre-activation): four k-tiles, nothing pending yet ----
+            chunk_bwd<-1, true, BLK>(pipe, cur, accA, hid[0], hid, accB, pd);
+            chunk_bwd<-1, false, BLK>(pipe, cur, accA, hid[1], hid, accB, pd);
+            chunk_bwd<-1, false, BLK>(pipe, cur, accA, hid[2], hid, accB, pd);
+            chunk_bwd<-1, false, BLK>(pipe, cur, accA, hid[3], hid, accB, pd);
+            make_pending(0, m_prev, pd.t_out);
+            // the alpha column's operand: d sigma as value 0 of half-wave 0 (the column k = 0 of its k-tile), at d feature's scale
+            clear_xs();
+            split_pair<0>(xs, dsig_h0 * pd.sc, 0.0f);
+        } else {
+            // ---- d h_{D-1} = W_output^T d raw: one k-tile whose columns 0..3 (half-wave 0) and 4..7 (half-wave 1) are the channels ----
+            const float sc = pow2f(t_head);
+            clear_xs();
+            split_pair<0>(xs, dr_head[0] * sc, dr_head[1] * sc);
+            split_pair<1>(xs, dr_head[2] * sc, dr_head[3] * sc);
+            chunk_bwd<-1, true, BLK>(pipe, cur, accA, xs, hid, accB, pd);
+            make_pending(1, m_prev, t_head);
+        }
 
         // ---- backward layers 1 .. D: layer bl accumulates into `out` while the pending layer bl - 1 is converted ----
         auto layer_pass = [&](f32x16 (&pend)[8], f32x16 (&out)[8], int bl_) {
@@ -313,8 +351,8 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
             // this layer's outputs will want their ReLU mask at its end: trunk layer D - bl's, requested now
             fetch(mask_rec(b.fwd.mask[D - bl], pt), 2);
             if (bl == D) {      // the last layer: the next tile's records (their slots were read in this tile's prologue)
-                fetch(b.d_raw + pt_next * 4, 0);
-                fetch(mask_rec(b.fwd.mask_hv, pt_next), 1);
+                fetch(d_raw_rec(pt_next), 0);
+                fetch(first_mask(pt_next), 1);
             }
             chunk_bwd<1, true, BLK>(pipe, cur, out, hid[0], hid, pend, pd);
             next_tile_pair<BLK>(pd);
@@ -328,10 +366,12 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
             chunk_bwd<7, false, BLK>(pipe, cur, out, hid[6], hid, pend, pd);
             chunk_bwd<-1, false, BLK>(pipe, cur, out, hid[7], hid, pend, pd);
             close_pending(bl == 1 ? kBwdMaxFeat : D - bl + 1);      // (pending: d feature, then d z_{D - bl + 1})
-            if (bl == 1) chunk_bwd<-1, false, BLK>(pipe, cur, out, xs, hid, pend, pd);      // + w_alpha d sigma (nerf.py:86)
+            if (VIEWS && bl == 1) chunk_bwd<-1, false, BLK>(pipe, cur, out, xs, hid, pend, pd);      // + w_alpha d sigma (nerf.py:86)
             make_pending(bl, m_prev, pd.t_out);
         };
-        int bl = 1;
+        // (the pending sums are in accA either way: d feature with backward layer 1 next, or - without view directions -
+        // d h_{D-1} with layer 2 next; the two accumulator sets alternate statically)
+        int bl = VIEWS ? 1 : 2;
         bool pend_in_a = true;
         while (bl <= D) {
             layer_pass(accA, accB, bl);
@@ -371,15 +411,18 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
 hipError_t launch_mlp_bwd_h2(const MlpBwdLaunch& b, hipStream_t s) {
     if (b.n_points <= 0) return hipSuccess;
     if (!b.stream_h2 || !b.descale || !b.gain || !b.bias || !b.d_raw) return hipErrorInvalidValue;
-    if (b.D < 1 || b.D > kMaxDepth || b.n_chunks != 13 + 8 * (b.D - 1) || b.C != 4) return hipErrorInvalidValue;
+    const bool views = b.use_viewdirs != 0;
+    // view-dependent: 4 + 8 + 1 chunks ahead of the trunk's, d raw [P, 4]; otherwise the head's one chunk, d raw [P, 8] (zero-padded)
+    if (b.D < (views ? 1 : 2) || b.D > kMaxDepth || b.n_chunks != (views ? 13 : 1) + 8 * (b.D - 1)) return hipErrorInvalidValue;
+    if (views ? b.C != 4 : (b.C < 1 || b.C > 8 || b.d_raw_ld != 8)) return hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(b.d_raw) & 15) != 0) return hipErrorInvalidValue;
     // one-instruction 16-byte stores: aligned rows, byte offsets below 2^32; 16-byte mask records
     auto ok = [&](const float* p, int ld) {
         return p != nullptr && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0 &&
                (uint64_t)b.n_points * (uint64_t)ld * 4u < ((uint64_t)1 << 32);
     };
-    bool rows_ok = ok(b.out.hv, b.out.hv_ld) && ok(b.out.feat, b.out.feat_ld) && b.fwd.mask_hv &&
-                   (reinterpret_cast<uintptr_t>(b.fwd.mask_hv) & 15) == 0;
+    bool rows_ok = !views || (ok(b.out.hv, b.out.hv_ld) && ok(b.out.feat, b.out.feat_ld) && b.fwd.mask_hv &&
+                              (reinterpret_cast<uintptr_t>(b.fwd.mask_hv) & 15) == 0);
     for (int i = 0; i < b.D; ++i)
         rows_ok = rows_ok && ok(b.out.h[i], b.out.h_ld[i]) && b.fwd.mask[i] && (reinterpret_cast<uintptr_t>(b.fwd.mask[i]) & 15) == 0;
     if (!rows_ok) return hipErrorInvalidValue;
@@ -396,16 +439,22 @@ hipError_t launch_mlp_bwd_h2(const MlpBwdLaunch& b, hipStream_t s) {
     }
     const dim3 grid((unsigned)(tiles < n_cu[dev] ? tiles : n_cu[dev])), block(256);
     const size_t lds = kRingH * kChunkBytes;
-    static bool raised[64][2] = {};
-    const int blk = b.out.blocked ? 1 : 0;
-    if (!raised[dev][blk]) {
-        e = hipFuncSetAttribute(blk ? (const void*)nerf_mlp_bwd_h2_kernel<true> : (const void*)nerf_mlp_bwd_h2_kernel<false>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool raised[64][4] = {};
+    const int blk = b.out.blocked ? 1 : 0, which = 2 * (views ? 1 : 0) + blk;
+    const void* fn = views ? (blk ? (const void*)nerf_mlp_bwd_h2_kernel<true, true> : (const void*)nerf_mlp_bwd_h2_kernel<false, true>)
+                           : (blk ? (const void*)nerf_mlp_bwd_h2_kernel<true, false> : (const void*)nerf_mlp_bwd_h2_kernel<false, false>);
+    if (!raised[dev][which]) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        raised[dev][blk] = true;
+        raised[dev][which] = true;
     }
-    if (blk) hipLaunchKernelGGL(nerf_mlp_bwd_h2_kernel<true>, grid, block, lds, s, b);
-    else hipLaunchKernelGGL(nerf_mlp_bwd_h2_kernel<false>, grid, block, lds, s, b);
+    if (views) {
+        if (blk) hipLaunchKernelGGL((nerf_mlp_bwd_h2_kernel<true, true>), grid, block, lds, s, b);
+        else hipLaunchKernelGGL((nerf_mlp_bwd_h2_kernel<false, true>), grid, block, lds, s, b);
+    } else {
+        if (blk) hipLaunchKernelGGL((nerf_mlp_bwd_h2_kernel<true, false>), grid, block, lds, s, b);
+        else hipLaunchKernelGGL((nerf_mlp_bwd_h2_kernel<false, false>), grid, block, lds, s, b);
+    }
     return hipGetLastError();
 }
 
@@ -433,7 +482,7 @@ __global__ __launch_bounds__(1024) void layer_gain_bwd_kernel(const float* param
     __syncthreads();
     if (threadIdx.x < 256) {
         sum = part[0][r] + part[1][r] + part[2][r] + part[3][r];
-        float am = (l == 1) ? fabsf(params[refs.alpha_off + r]) : 0.0f;
+        float am = (l == 1 && refs.alpha_off != 0xffffffffu) ? fabsf(params[refs.alpha_off + r]) : 0.0f;
         for (int o = 32; o > 0; o >>= 1) {
             sum = fmaxf(sum, __shfl_xor(sum, o));
             am = fmaxf(am, __shfl_xor(am, o));
@@ -453,20 +502,27 @@ __global__ __launch_bounds__(1024) void layer_gain_bwd_kernel(const float* param
 BwdGainRefs bwd_gain_refs(const nerf_arch& a, const std::vector<LinearDesc>& linears, uint32_t skip_in_mask) {
     BwdGainRefs r{};
     r.n = a.D + 1;
-    const LinearDesc &views = linears[a.D], &feat = linears[a.D + 1], &alpha = linears[a.D + 2];
     auto set = [&](int b, const LinearDesc& d, int col0) {
         r.w_off[b] = (unsigned)d.w_off;
         r.ld[b] = d.in;
         r.rows[b] = d.out;
         r.col0[b] = col0;
     };
-    set(0, views, 0);
-    set(1, feat, 0);
+    if (a.use_viewdirs) {
+        const LinearDesc &views = linears[a.D], &feat = linears[a.D + 1], &alpha = linears[a.D + 2];
+        set(0, views, 0);
+        set(1, feat, 0);
+        r.alpha_off = (unsigned)alpha.w_off;
+    } else {
+        // the chain starts at backward layer 1 = W_output^T (linears[D + 1]); layer 0 does not exist (its gain is unused)
+        set(0, linears[a.D + 1], 0);
+        set(1, linears[a.D + 1], 0);
+        r.alpha_off = 0xffffffffu;      // (no alpha column: layer_gain_bwd_kernel leaves gain[3] at 0)
+    }
     for (int b = 2; b <= a.D; ++b) {
         const int i = a.D - b + 1;
         set(b, linears[i], ((skip_in_mask >> i) & 1) ? a.input_ch : 0);
     }
-    r.alpha_off = (unsigned)alpha.w_off;
     return r;
 }
 

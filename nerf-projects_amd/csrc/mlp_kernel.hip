@@ -600,7 +600,7 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
         const int64_t pt_raw = tile * kPointsPerGroup + wave * kPointsPerWave + (lane & 31);
         const int64_t pt = pt_raw < b.n_points ? pt_raw : b.n_points - 1;
         const bool live = pt_raw < b.n_points;
-        const float* dr = b.d_raw + pt * b.C;
+        const float* dr = b.d_raw + pt * (b.d_raw_ld ? b.d_raw_ld : b.C);
         f32x16 hid[8], acc[8];
         if (b.use_viewdirs) {
             const float d0 = dr[0], d1 = dr[1], d2 = dr[2], dsig = dr[3];
@@ -659,7 +659,9 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
             if (b.maxes) track_max<8>(b.maxes + b.D - 1, hid);
         } else {
             // output_linear (nerf.py:109): d h_{D-1} = W_output^T d raw over the C <= kBwdMaxOutRows channels (rows per register:
-            // bias-block tiles 8D+1+8c+t), masked by the kept h_{D-1}
+            // bias-block tiles 8D+1+8c+t), masked by the kept h_{D-1}. (The stream carries the head as one MFMA chunk for the
+            // fp16-pair kernel; this kernel only keeps the ring turning over it.)
+            consume_chunk<8>(pipe, cur, [&](auto, auto, const Frag16&) {});
             zero_tiles<8>(acc);
             for (int c = 0; c < b.C; ++c) {
                 const float dc = dr[c];
@@ -701,7 +703,7 @@ void nerf_mlp_bwd_kernel(const MlpBwdLaunch b) {
 
 hipError_t launch_mlp_bwd(const MlpBwdLaunch& b, hipStream_t s) {
     if (b.n_points <= 0) return hipSuccess;
-    if (b.n_chunks != (b.use_viewdirs ? 13 : 0) + 8 * (b.D - 1) || b.C < 4) return hipErrorInvalidValue;
+    if (b.n_chunks != (b.use_viewdirs ? 13 : 1) + 8 * (b.D - 1) || b.C < 4) return hipErrorInvalidValue;
     if (!b.use_viewdirs && (b.C > kBwdMaxOutRows || b.n_bias_tiles < 8 * b.D + 1 + 8 * b.C || b.D < 2)) return hipErrorInvalidValue;
     if (b.n_points > (int64_t)1 << 22) return hipErrorInvalidValue;      // 32-bit element offsets in load/store_tiles
     // the hooks inside the chunk loop are unconditional 16-byte accesses (RowRef)

@@ -598,15 +598,20 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
                 *(f32x4*)(a.out + pt * 4) = o;
             }
         } else {
-            // output_linear (nerf.py:109): rows 0..out_ch-1 of one tile; the pending layer is trunk layer D-1
-            convert_tile0_with(hid[0], accA[0], pd, bias0_req);
-            convert_tile<1>(hid[1], accA[1], pd);
-            convert_tile<2>(hid[2], accA[2], pd);
-            convert_tile<3>(hid[3], accA[3], pd);
-            convert_tile<4>(hid[4], accA[4], pd);
-            convert_tile<5>(hid[5], accA[5], pd);
-            convert_tile<6>(hid[6], accA[6], pd);
-            convert_tile<7>(hid[7], accA[7], pd);
+            // output_linear (nerf.py:109): rows 0..out_ch-1 of one tile; the pending layer is trunk layer D-1 (STORE: kept, with
+            // its mask record and maximum, like every other trunk layer - the training pass of networks without view directions)
+            convert_tile0_with<STORE>(hid[0], accA[0], pd, bias0_req);
+            convert_tile<1, STORE>(hid[1], accA[1], pd);
+            next_tile_pair<STORE>(pd);
+            convert_tile<2, STORE>(hid[2], accA[2], pd);
+            convert_tile<3, STORE>(hid[3], accA[3], pd);
+            next_tile_pair<STORE>(pd);
+            convert_tile<4, STORE>(hid[4], accA[4], pd);
+            convert_tile<5, STORE>(hid[5], accA[5], pd);
+            next_tile_pair<STORE>(pd);
+            convert_tile<6, STORE>(hid[6], accA[6], pd);
+            convert_tile<7, STORE>(hid[7], accA[7], pd);
+            if constexpr (STORE != 0) close_pending(kBwdMaxKept + a.D - 1);
             const bool poisoned = !(half_max(pd.m) < __builtin_inff());      // the trunk overflowed on this point (make_pending)
             f32x16 o;
             chunk_row8(pipe, cur, o, hid);
@@ -660,15 +665,16 @@ hipError_t launch_mlp_h2(const MlpLaunch& a, int mode, hipStream_t s) {
     if (a.store) {
         // training forward: ray records, a view-dependent network, buffers the one-instruction stores can address
         // (16-byte aligned rows, byte offsets below 2^32)
-        if (mode != kInputRays || !a.use_viewdirs) return hipErrorInvalidValue;
+        if (mode != kInputRays) return hipErrorInvalidValue;
         auto ok = [&](const float* b, int ld) {
             return b != nullptr && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0 &&
                    (uint64_t)a.n_points * (uint64_t)ld * 4u < ((uint64_t)1 << 32);
         };
-        bool rows_ok = ok(a.st.feat, a.st.feat_ld) && ok(a.st.hv, a.st.hv_ld);
+        // (without view directions - output_linear on the trunk, nerf.py:109 - there is no feature vector and no view layer)
+        bool rows_ok = !a.use_viewdirs || (ok(a.st.feat, a.st.feat_ld) && ok(a.st.hv, a.st.hv_ld));
         for (int i = 0; i < a.D; ++i) rows_ok = rows_ok && ok(a.st.h[i], a.st.h_ld[i]);
         // the ReLU-mask records (32 bytes per point, byte offsets below 2^32) and the maxima are always written
-        rows_ok = rows_ok && a.st.maxes && a.st.mask_hv && (uint64_t)a.n_points * 32u < ((uint64_t)1 << 32);
+        rows_ok = rows_ok && a.st.maxes && (a.st.mask_hv || !a.use_viewdirs) && (uint64_t)a.n_points * 32u < ((uint64_t)1 << 32);
         for (int i = 0; i < a.D; ++i) rows_ok = rows_ok && a.st.mask[i] && (reinterpret_cast<uintptr_t>(a.st.mask[i]) & 15) == 0;
         if (!rows_ok) return hipErrorInvalidValue;
         static bool raised_store[64][2] = {};
@@ -810,7 +816,7 @@ struct EqualiseBatch {
     int* row_exp[2];
     float* out[2];
     EqualiseRefs refs[2];
-    unsigned* flags[2];      // row_exponents_layers_kernel: [kMaxLinears] per network, flag k = `epoch` once linear k's row is written
+    unsigned* flags[2];      // row_exponents_layers_kernel: the mailbox [kMaxLinears][256] per network: (epoch << 8) | (e_j + 128)
     unsigned epoch;
 #ifdef NERF_ROWEXP_STAMPS      // profiles/microbench/row_exponents_bench.hip: wall_clock64() samples of thread 0 per phase
     unsigned long long* stamps;
@@ -969,8 +975,8 @@ __global__ __launch_bounds__(kRowExpThreads) void row_exponents_kernel(const Equ
 // memory, reads the producer's exponents and finishes in a few microseconds. The chain's latency is a flag, sixteen rows of
 // arithmetic, a histogram and a median per layer instead of a layer's worth of memory latency: 0.10 -> 0.03 ms per training
 // iteration. Same expressions in the same order per row as row_exponents_kernel: the same table, bit for bit. All r.n x n
-// workgroups are resident at once (two dozen on 256 CUs), so the waiting ones cannot starve their producers; flags carry the
-// launch's epoch and need no reset.
+// workgroups are resident at once (two dozen on 256 CUs), so the waiting ones cannot starve their producers; the mailbox words
+// carry the launch's epoch (24 bits) and need no reset.
 __global__ __launch_bounds__(kRowExpThreads) void row_exponents_layers_kernel(const EqualiseBatch batch) {
     const int net = blockIdx.y;
     const float* params = batch.params[net];
@@ -986,14 +992,20 @@ __global__ __launch_bounds__(kRowExpThreads) void row_exponents_layers_kernel(co
     __shared__ int median_exp, n_valid;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = kRowExpThreads >> 6;
     const int n_out = r.out[k], n_in = r.in[k], src = r.col_src[k], c0 = r.hid_col0[k], c1 = c0 + r.n_hid[k];
-    auto publish = [&]() {
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(&flags[k], batch.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // Producer and consumer may sit on different XCDs, whose L2s are not coherent with each other. A release fence at agent scope
+    // writes the whole L2's dirty lines back - gigabytes of the step's traffic pass through it: measured 126 us for the chain,
+    // slower than one workgroup walking it - so nothing here is a fence: the exponents and the flag are device-scope atomic stores
+    // (written through to where every XCD sees them), the flag goes out after every thread's stores have been acknowledged
+    // (s_waitcnt + barrier), and the consumer reads both with device-scope atomic loads, flag first.
+    // Each exponent travels with its own flag: the mailbox word (epoch << 8 | e + 128) of unit j is what the consumer's thread j
+    // polls - one round trip through memory per layer of the chain, no separate flag, no barrier on the producer's side (the
+    // table itself is written with plain stores for the kernels that follow this launch).
+    auto put = [&](int j, int e) {
+        row_exp_out[k * 256 + j] = e;
+        __hip_atomic_store(&flags[k * 256 + j], (batch.epoch << 8) | (unsigned)(e + 128), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     if (!r.scale_rows[k]) {
-        for (int j = threadIdx.x; j < 256; j += blockDim.x) row_exp_out[k * 256 + j] = 0;
-        publish();
+        for (int j = threadIdx.x; j < 256; j += blockDim.x) put(j, 0);
         return;
     }
     constexpr int kRows = 4, kCols = 6, kRounds = 4;      // 16 waves x 4 rows x 4 rounds = 256 rows; 64 x 6 columns cover in <= 383
@@ -1021,12 +1033,12 @@ __global__ __launch_bounds__(kRowExpThreads) void row_exponents_layers_kernel(co
     for (int q = threadIdx.x; q < kExpBins; q += blockDim.x) hist[q] = 0;
     if (threadIdx.x == 0) n_valid = 0;
     // ---- phase 2: the producer's exponents ----
-    if (src >= 0) {
-        if (threadIdx.x == 0)
-            while (__hip_atomic_load(&flags[src], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != batch.epoch) __builtin_amdgcn_s_sleep(1);
-        __syncthreads();
-        for (int j = threadIdx.x; j < 256; j += blockDim.x)
-            expo_src[j] = __hip_atomic_load(&row_exp_out[src * 256 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (src >= 0 && threadIdx.x < 256) {
+        unsigned w;
+        while (((w = __hip_atomic_load(&flags[src * 256 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 8) !=
+               (batch.epoch & 0xffffffu))
+            __builtin_amdgcn_s_sleep(1);
+        expo_src[threadIdx.x] = (int)(w & 0xffu) - 128;
     }
     __syncthreads();
     int nec[kCols];                            // this lane's columns: minus the producer's exponent
@@ -1105,9 +1117,8 @@ __global__ __launch_bounds__(kRowExpThreads) void row_exponents_layers_kernel(co
     for (int j = threadIdx.x; j < 256; j += blockDim.x) {
         int e = (j < n_out && row_exp[j] > -1000) ? median_exp - row_exp[j] : 0;
         e = e > 30 ? 30 : (e < -30 ? -30 : e);
-        row_exp_out[k * 256 + j] = e;
+        put(j, e);
     }
-    publish();
 }
 
 // out[k][j][c] = params[k][j][c] * 2^(e_kj - e_src(k),c) (row_exponents_kernel's table; exact): the copy of the network the

@@ -201,6 +201,7 @@ struct MlpBwdLaunch {
     int64_t n_points;
     const float* d_raw;      // [P, C]: d rgb (0..2), d sigma (3)
     int C;
+    int d_raw_ld;            // row stride of d_raw in floats (fp16-pair kernel without view directions: 8, zero-padded; else C)
     int use_viewdirs;        // 0: output_linear head (C <= kBwdMaxOutRows rows, nerf.py:109): fp32 kernel only
     MlpStore fwd;            // the activations the forward pass kept (ReLU masks): h[i], hv
     MlpStore out;            // h[i] = d(pre-activation of trunk layer i), feat = d feature, hv = d(view pre-activation)
@@ -431,6 +432,7 @@ struct TrainEpilogue {
     int white_bkgd;
     // the last pass (the fine one, or the only one)
     const float* raw_l; int C_l; const float* z_l; const float* noise_l; int S_l; float* d_raw_l;
+    int dC_l, dC_c;          // row strides of d_raw_l / d_raw_c (0 = C)
     // the coarse pass when a fine one follows it (raw_c = nullptr otherwise): its colours come from the mid launch
     const float* raw_c; int C_c; const float* z_c; const float* noise_c; int S_c; float* d_raw_c; const float* rgb_c;
     float* out_rgb;          // [N,3] the last pass's colours (the caller's buffer, or scratch)
@@ -445,7 +447,7 @@ hipError_t launch_train_epilogue(const TrainEpilogue& e, hipStream_t s);
 hipError_t launch_train_stats(const float* loss, bool two, float* stats, hipStream_t s);
 hipError_t launch_composite_bwd(const float* raw, int C, const float* z, const float* rays_d, int d_ld,
                                 const float* noise, int white_bkgd, int64_t N, int S, const float* g_rgb,
-                                float* d_raw, hipStream_t s);
+                                float* d_raw, hipStream_t s, int dC = 0);      // dC: row stride of d_raw (0 = C)
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                        int step, hipStream_t s);
 hipError_t launch_transpose(const float* src, int rows, int cols, float* dst, hipStream_t s);

@@ -121,6 +121,7 @@ std::vector<int> chunk_layers(const nerf_arch& a, uint32_t mask) {
 //             + w_alpha d sigma                              1 chunk: the alpha row as the column k = 0 of a k-tile, for the
 //                                                            fp16-pair kernel (d sigma rides as one more operand value);
 //                                                            the fp32 kernel adds the rank-1 term itself and passes over it
+//   (without view directions: d h_{D-1} = W_output^T d raw  1 chunk instead of those thirteen)
 //   d h_{i-1} = W_i[:, hidden columns]^T d z_i, i = D-1..1   8 chunks each
 // `tensors` in state_dict order as for pack_weights; validated there.
 int pack_backward_stream(const nerf_arch& a, const float* const* tensors, uint32_t mask, float** stream_out,
@@ -139,7 +140,13 @@ int pack_backward_stream(const nerf_arch& a, const float* const* tensors, uint32
         layer(LinearT{tensors[2 * a.D], a.W, a.W / 2, a.W + a.input_ch_views, 0}, 4);
         layer(LinearT{head[0], a.W, a.W, a.W, 0}, 8);
         chunk_ktile(st, ColumnOf{head[2], a.W}, 8, [](int t, int h) { return hid_col(0, t, h); });
-    }      // (without view directions the chain starts at d h_{D-1} = W_output^T d raw, a vector product in the kernel)
+    } else {
+        // without view directions the chain starts at d h_{D-1} = W_output^T d raw (nerf.py:109): the head's C <= 8 rows as the
+        // columns 0..C-1 of one k-tile for the fp16-pair kernel (d raw is its operand: channels 0-3 in half-wave 0, 4-7 in
+        // half-wave 1 - the places hid_col gives columns 0-7); the fp32 kernel forms the product from the rows in the bias block
+        // and passes over the chunk
+        chunk_ktile(st, LinearT{head[0], a.W, a.output_ch, a.W, 0}, 8, [](int t, int h) { return hid_col(0, t, h); });
+    }
     for (int i = a.D - 1; i >= 1; --i) {
         const bool pe_in = (mask >> i) & 1;
         layer(LinearT{tensors[2 * i], a.W, a.W, pe_in ? a.W + a.input_ch : a.W, pe_in ? a.input_ch : 0}, 8);

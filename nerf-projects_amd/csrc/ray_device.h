@@ -243,12 +243,12 @@ __device__ __forceinline__ void sample_pdf_ray(int64_t ray, int lane, char* smem
 __device__ __forceinline__ void composite_bwd_ray(int64_t ray, int lane, float* Tsh, const float* __restrict__ raw, int C,
                                                   const float* __restrict__ z_vals, const float* __restrict__ rays_d, int d_ld,
                                                   const float* __restrict__ noise, int white_bkgd, int S, float g0, float g1,
-                                                  float g2, float* __restrict__ d_raw) {
+                                                  float g2, float* __restrict__ d_raw, int dC) {      // dC: row stride of d_raw (>= C; the rest zeroed)
     const float* d = rays_d + ray * d_ld;
     const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
     const float* z = z_vals + ray * S;
     const float* rw = raw + ray * (int64_t)S * C;
-    float* dr = d_raw + ray * (int64_t)S * C;
+    float* dr = d_raw + ray * (int64_t)S * dC;
     const float gbg = white_bkgd ? (g0 + g1 + g2) : 0.0f;
 
     auto alpha_at = [&](int i, float& dist, float& sig) {
@@ -302,11 +302,11 @@ __device__ __forceinline__ void composite_bwd_ray(int64_t ray, int lane, float* 
         if (on) {
             const float om = __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f);
             const float dalpha_dsig = sig > 0.0f ? dist * (1.0f - alpha) : 0.0f;   // d/dsigma of 1 - exp(-relu(sigma) dist)
-            dr[(int64_t)i * C + 0] = g0 * wi * c0 * (1.0f - c0);
-            dr[(int64_t)i * C + 1] = g1 * wi * c1 * (1.0f - c1);
-            dr[(int64_t)i * C + 2] = g2 * wi * c2 * (1.0f - c2);
-            dr[(int64_t)i * C + 3] = dalpha_dsig * (T * (gc - gbg) - suffix_excl / om);
-            for (int c = 4; c < C; ++c) dr[(int64_t)i * C + c] = 0.0f;
+            dr[(int64_t)i * dC + 0] = g0 * wi * c0 * (1.0f - c0);
+            dr[(int64_t)i * dC + 1] = g1 * wi * c1 * (1.0f - c1);
+            dr[(int64_t)i * dC + 2] = g2 * wi * c2 * (1.0f - c2);
+            dr[(int64_t)i * dC + 3] = dalpha_dsig * (T * (gc - gbg) - suffix_excl / om);
+            for (int c = 4; c < dC; ++c) dr[(int64_t)i * dC + c] = 0.0f;
         }
     }
 }

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(1024) void refresh_convert_kernel(const RefreshBatc
             __syncthreads();
             if (threadIdx.x < 256) {
                 sum = part[0][r] + part[1][r] + part[2][r] + part[3][r];
-                float am = (l == 1) ? fabsf(params[refs.alpha_off + r]) : 0.0f;
+                float am = (l == 1 && refs.alpha_off != 0xffffffffu) ? fabsf(params[refs.alpha_off + r]) : 0.0f;
                 for (int o = 32; o > 0; o >>= 1) {
                     sum = fmaxf(sum, __shfl_xor(sum, o));
                     am = fmaxf(am, __shfl_xor(am, o));

@@ -56,9 +56,14 @@ int mark_params_changed(PackedNet& net, hipStream_t s, bool stepped) {
 
 // scale group of every chunk of the backward stream (pack_backward_stream): one per transposed matrix
 std::vector<int> bwd_chunk_layers(const nerf_arch& a) {
-    std::vector<int> ids(4, 0);
-    ids.insert(ids.end(), 8, 1);
-    ids.insert(ids.end(), 1, 1);       // the alpha column shares feature_linear's scale
+    std::vector<int> ids;
+    if (a.use_viewdirs) {
+        ids.assign(4, 0);
+        ids.insert(ids.end(), 8, 1);
+        ids.insert(ids.end(), 1, 1);       // the alpha column shares feature_linear's scale
+    } else {
+        ids.assign(1, 1);                  // W_output^T: backward layer 1 of the chain without view directions
+    }
     for (int b = 2; b <= a.D; ++b) ids.insert(ids.end(), 8, b);
     return ids;
 }
@@ -134,8 +139,8 @@ int refresh_after_step(nerf_ctx* c, PackedNet* const* nets, int n, hipStream_t s
     for (int i = 0; i < n; ++i) {
         PackedNet& net = *nets[i];
         if (!net.d_eq_flags) {
-            HIP_TRY(hipMalloc((void**)&net.d_eq_flags, kMaxLinears * sizeof(unsigned)));
-            HIP_TRY(hipMemsetAsync(net.d_eq_flags, 0, kMaxLinears * sizeof(unsigned), s));
+            HIP_TRY(hipMalloc((void**)&net.d_eq_flags, kMaxLinears * 256 * sizeof(unsigned)));
+            HIP_TRY(hipMemsetAsync(net.d_eq_flags, 0, kMaxLinears * 256 * sizeof(unsigned), s));
             net.eq_epoch = 0;
         }
         flags[i] = net.d_eq_flags;
@@ -143,7 +148,7 @@ int refresh_after_step(nerf_ctx* c, PackedNet* const* nets, int n, hipStream_t s
     // (one epoch for the launch: both networks' counters move together; 0 is the value of a fresh flag and is skipped)
     unsigned epoch = nets[0]->eq_epoch + 1;
     if (n > 1 && nets[1]->eq_epoch + 1 > epoch) epoch = nets[1]->eq_epoch + 1;
-    if (epoch == 0) epoch = 1;
+    if ((epoch & 0xffffffu) == 0) epoch += 1;      // (24 bits travel in a mailbox word; 0 is a fresh word's)
     for (int i = 0; i < n; ++i) nets[i]->eq_epoch = epoch;
     HIP_TRY(launch_equalise_rows(n, params, refs, out, rexp, s, flags, epoch));
     RefreshBatch b{};
@@ -201,6 +206,7 @@ struct Pass {              // one network evaluated at P = N*S points with every
     unsigned* mask[kMaxDepth] = {};   // ReLU masks of the trunk layers, one bit per unit (MlpStore::mask), and the view layer's
     unsigned* mask_hv = nullptr;
     int vcat_ld = 0, C = 4;
+    int dC = 4;              // row stride of d_raw (8, zero-padded, where the fp16-pair backward kernel reads a head of C <= 8 channels)
     // The kept activations and the gradients at the pre-activations BLOCKED by 32 points (MlpStore::blocked) instead of row-major:
     // h[i], feat_blk (the feature vector; vcat then holds gamma(d) alone, voff = 0), dz[i], g_a (d feature), g_hv. Only when every
     // producer and consumer is one of the fp16-pair kernels that know the layout (set_units).
@@ -285,7 +291,8 @@ void carve_pass(Arena& ar, Pass& ps) {
         ps.hv = ar.take((size_t)P * (a.W / 2));
     }
     ps.raw = ar.take((size_t)P * ps.C);
-    ps.d_raw = ar.take((size_t)P * ps.C);
+    ps.dC = (ps.pair_backward && !a.use_viewdirs) ? 8 : ps.C;
+    ps.d_raw = ar.take((size_t)P * ps.dC);
     const size_t rows = ps.blocked ? Pg : (size_t)P;
     ps.g_a = ar.take(rows * a.W);
     ps.g_b = ar.take((size_t)P * a.W);
@@ -750,19 +757,21 @@ int backward_pass_fused_noviews(Pass& ps, const TnScratch& sc, hipStream_t s) {
     const PackedNet& net = *ps.net;
     const nerf_arch& a = net.arch;
     const LinearDesc &views = net.linears[a.D], &out = net.linears[a.D + 1];
+    const bool eq = ps.eq;
     {
-        const int rc = refresh_bwd(const_cast<PackedNet&>(net), false, false, s);
+        const int rc = refresh_bwd(const_cast<PackedNet&>(net), eq, ps.pair_backward, s);
         if (rc != NERF_OK) return rc;
     }
     MlpBwdLaunch b{};
     b.stream = net.train.d_stream_bwd;
     b.n_chunks = net.train.n_chunks_bwd;
-    b.bias = net.d_bias;
+    b.bias = eq ? net.d_bias_h2 : net.d_bias;
     b.n_bias_tiles = net.n_bias_tiles;
     b.D = a.D;
     b.n_points = ps.P;
     b.d_raw = ps.d_raw;
     b.C = ps.C;
+    b.d_raw_ld = ps.dC;
     b.use_viewdirs = 0;
     for (int i = 0; i < a.D; ++i) {
         b.fwd.h[i] = ps.h[i];
@@ -771,13 +780,22 @@ int backward_pass_fused_noviews(Pass& ps, const TnScratch& sc, hipStream_t s) {
         b.out.h_ld[i] = a.W;
     }
     const bool pair_dw = ps.precision == NERF_PRECISION_F16X2 && pair_dw_allowed() && ps.maxes != nullptr;
-    if (pair_dw) b.maxes = ps.maxes;
-    {
+    if (pair_dw || ps.pair_backward) b.maxes = ps.maxes;
+    if (ps.pair_backward) {
+        // the fp16-pair kernel on the equalised transposed weights: W_output^T is the chain's first chunk, the masks are bits
+        b.stream_h2 = net.train.d_stream_bwd_h2;
+        b.descale = net.train.d_descale_bwd;
+        b.gain = net.train.d_gain_bwd;
+        b.loose = ps.loose;
+        for (int i = 0; i < a.D; ++i) b.fwd.mask[i] = ps.mask[i];
+        TrainTimer timer(ps.ctx, s, 1, ps.P);
+        HIP_TRY(launch_mlp_bwd_h2(b, s));
+    } else {
         TrainTimer timer(ps.ctx, s, 1, ps.P);
         HIP_TRY(launch_mlp_bwd(b, s));
     }
     int rc;
-    if ((rc = grad_linear(net, out, ps.d_raw, ps.C, ps.h[a.D - 1], ps.h_ld[a.D - 1], ps.P, sc, s))) return rc;
+    if ((rc = grad_linear(net, out, ps.d_raw, ps.dC, ps.h[a.D - 1], ps.h_ld[a.D - 1], ps.P, sc, s, eq))) return rc;
     if (!sc.accumulate)
         HIP_TRY(hipMemsetAsync(net.train.d_grad + views.w_off, 0, ((size_t)views.out * views.in + views.out) * sizeof(float), s));
     float* grad = net.train.d_grad;
@@ -785,11 +803,11 @@ int backward_pass_fused_noviews(Pass& ps, const TnScratch& sc, hipStream_t s) {
     auto job = [&](GradBatch& bt, const LinearDesc& d, const float* dY, const float* X, int ldx, int n0, int n1, bool with_db,
                    const unsigned* a_max = nullptr, const unsigned* b_max = nullptr) {
         bt.job[bt.n++] = GradJob{dY, a.W, X, ldx, d.out, n0, n1, grad + d.w_off, d.in, with_db ? grad + d.b_off : nullptr,
-                                 nullptr, nullptr, a_max, b_max, GradExps{nullptr, nullptr, 0, 0}};
+                                 nullptr, nullptr, a_max, b_max, grad_exps(net, (int)(&d - &net.linears[0]), eq)};
     };
     if (a.input_ch > 64 || a.D > kMaxGradJobs) {
         for (int i = a.D - 1; i >= 0; --i)
-            if ((rc = grad_linear(net, net.linears[i], ps.dz[i], a.W, ps.in[i], ps.in_ld[i], ps.P, sc, s))) return rc;
+            if ((rc = grad_linear(net, net.linears[i], ps.dz[i], a.W, ps.in[i], ps.in_ld[i], ps.P, sc, s, eq))) return rc;
         return NERF_OK;
     }
     GradBatch& hidden = pair_dw ? pairs : wide;
@@ -886,7 +904,14 @@ int backward_pass(Pass& ps, const TnScratch& sc, hipStream_t s) {
 void set_units(Pass& ps) {
     const nerf_arch& a = ps.net->arch;
     const bool fused_forward = !gemm_forward_requested() && a.D <= kMaxDepth && a.W == kWidth;
-    ps.eq = ps.precision == NERF_PRECISION_F16X2 && pair_forward_allowed() && fused_forward && a.use_viewdirs &&
+    // (networks without view directions, round 4: the same three fp16-pair kernels, output_linear as one more chunk in both
+    // directions - when the whole pass can stay on them: a head of <= 8 channels and the fused backward stream, api.cpp)
+    static const bool noviews_pair = [] {      // NERF_TRAIN_NOVIEWS=f32: the fused fp32 kernels for them (A/B)
+        const char* e = getenv("NERF_TRAIN_NOVIEWS");
+        return !(e && (e[0] == 'f' || e[0] == 'F') && e[1] == '3');
+    }();
+    const bool arch_ok = a.use_viewdirs || (noviews_pair && ps.fused_backward && pair_bwd_allowed() && ps.net->out_ch <= 8 && a.D >= 2);
+    ps.eq = ps.precision == NERF_PRECISION_F16X2 && pair_forward_allowed() && fused_forward && arch_ok &&
             (uint64_t)ps.P * (uint64_t)(a.W + a.input_ch + 4) * 4u < ((uint64_t)1 << 32);
     ps.pair_backward = ps.eq && ps.fused_backward && pair_bwd_allowed();
     // Blocked by 32 points (MlpStore::blocked; NERF_TRAIN_BLOCKED=0: row-major, the A/B switch): when the three fp16-pair
@@ -902,7 +927,7 @@ void set_units(Pass& ps) {
     }();
     ps.blocked = blocked_wanted && ps.pair_backward && pair_dw_allowed() && rider_on && grad_pair_takes_riders() &&
                  gemm_tn_is_direct(a.W) && gemm_tn_is_direct(a.W / 2) && a.input_ch <= 64 && a.input_ch_views <= 64 &&
-                 a.D + 2 <= kMaxGradJobs && ps.net->out_ch == 4 && (uint64_t)ps.P * 1024u < ((uint64_t)1 << 32);
+                 a.D + 2 <= kMaxGradJobs && a.use_viewdirs && ps.net->out_ch == 4 && (uint64_t)ps.P * 1024u < ((uint64_t)1 << 32);
 }
 
 }  // namespace
@@ -1037,6 +1062,8 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
         if (Si) {
             HIP_TRY(launch_train_mid(pc.raw, pc.C, z_c, r->rays + 3, r->ray_stride, r->noise0, r->white_bkgd, N, Sc, rgb_c, w_c,
                                      r->perturb ? r->u_rand : nullptr, Si, z_f, s));      // z_samples are detached (nerf.ipynb:464)
+            if (r->z_vals_fine_in)      // (parity tests: the fine pass at the reference's depths)
+                HIP_TRY(hipMemcpyAsync(z_f, r->z_vals_fine_in, (size_t)N * Sf * sizeof(float), hipMemcpyDeviceToDevice, s));
             if ((rc = forward_pass(pf, r->rays, r->ray_stride, z_f, s))) return rc;
         }
         // ---- raw2outputs of the last pass, loss = img2mse(rgb, target) [+ img2mse(rgb0, target)] (nerf.ipynb:1262-1272),
@@ -1050,8 +1077,9 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
         e.white_bkgd = r->white_bkgd;
         e.raw_l = pl.raw; e.C_l = pl.C; e.z_l = Si ? z_f : z_c; e.noise_l = Si ? r->noise : r->noise0; e.S_l = Si ? Sf : Sc;
         e.d_raw_l = pl.d_raw;
+        e.dC_l = pl.dC;
         if (Si) {
-            e.raw_c = pc.raw; e.C_c = pc.C; e.z_c = z_c; e.noise_c = r->noise0; e.S_c = Sc; e.d_raw_c = pc.d_raw; e.rgb_c = rgb_c;
+            e.raw_c = pc.raw; e.C_c = pc.C; e.z_c = z_c; e.noise_c = r->noise0; e.S_c = Sc; e.d_raw_c = pc.d_raw; e.dC_c = pc.dC; e.rgb_c = rgb_c;
         }
         e.out_rgb = r->rgb_map ? r->rgb_map : rgb_last;
         e.out_rgb0 = Si ? r->rgb0 : nullptr;
@@ -1082,6 +1110,8 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
     if (Si) {
         HIP_TRY(launch_sample_pdf(nullptr, w_c, Sc, 1, z_c, r->perturb ? r->u_rand : nullptr, N, Sc - 1, Si, z_s, z_f,
                                   nullptr, s));                     // z_samples are detached (nerf.ipynb:464)
+        if (r->z_vals_fine_in)
+            HIP_TRY(hipMemcpyAsync(z_f, r->z_vals_fine_in, (size_t)N * Sf * sizeof(float), hipMemcpyDeviceToDevice, s));
         if ((rc = forward_pass(pf, r->rays, r->ray_stride, z_f, s))) return rc;
         HIP_TRY(launch_composite(pf.raw, pf.C, z_f, r->rays + 3, r->ray_stride, r->noise, r->white_bkgd, N, Sf, rgb_f,
                                  nullptr, nullptr, w_f, nullptr, s));
@@ -1098,13 +1128,13 @@ int nerf_train_step(nerf_ctx* c, const nerf_train_args* r) {
 
     // ---- backward ----
     HIP_TRY(launch_composite_bwd(pc.raw, pc.C, z_c, r->rays + 3, r->ray_stride, r->noise0, r->white_bkgd, N, Sc, g_c,
-                                 pc.d_raw, s));
+                                 pc.d_raw, s, pc.dC));
     sc.P = Pc;
     if ((rc = backward_pass(pc, sc, s))) return rc;
     nc.train.grads_valid = true;
     if (Si) {
         HIP_TRY(launch_composite_bwd(pf.raw, pf.C, z_f, r->rays + 3, r->ray_stride, r->noise, r->white_bkgd, N, Sf, g_f,
-                                     pf.d_raw, s));
+                                     pf.d_raw, s, pf.dC));
         sc.P = Pf;
         sc.accumulate = shared ? 1 : 0;
         if ((rc = backward_pass(pf, sc, s))) return rc;

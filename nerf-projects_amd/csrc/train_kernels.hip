@@ -842,19 +842,19 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
                                                            const float* __restrict__ z_vals,
                                                            const float* __restrict__ rays_d, int d_ld,
                                                            const float* __restrict__ noise, int white_bkgd, int S,
-                                                           const float* __restrict__ g_rgb, float* __restrict__ d_raw) {
+                                                           const float* __restrict__ g_rgb, float* __restrict__ d_raw, int dC) {
     extern __shared__ float Tsh[];   // exclusive transmittance of every sample of this ray
     const int64_t ray = blockIdx.x;
     composite_bwd_ray(ray, threadIdx.x, Tsh, raw, C, z_vals, rays_d, d_ld, noise, white_bkgd, S, g_rgb[ray * 3 + 0],
-                      g_rgb[ray * 3 + 1], g_rgb[ray * 3 + 2], d_raw);
+                      g_rgb[ray * 3 + 1], g_rgb[ray * 3 + 2], d_raw, dC);
 }
 
 hipError_t launch_composite_bwd(const float* raw, int C, const float* z, const float* rays_d, int d_ld,
                                 const float* noise, int white_bkgd, int64_t N, int S, const float* g_rgb,
-                                float* d_raw, hipStream_t s) {
+                                float* d_raw, hipStream_t s, int dC) {
     if (N <= 0) return hipSuccess;
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)N), dim3(64), (size_t)S * sizeof(float), s, raw, C, z,
-                       rays_d, d_ld, noise, white_bkgd, S, g_rgb, d_raw);
+                       rays_d, d_ld, noise, white_bkgd, S, g_rgb, d_raw, dC > 0 ? dC : C);
     return hipGetLastError();
 }
 
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(64) void train_epilogue_kernel(const TrainEpilogue 
     const float d0 = __fsub_rn(rgb_sh[0], t0), d1 = __fsub_rn(rgb_sh[1], t1), d2 = __fsub_rn(rgb_sh[2], t2);
     double sq_l = (double)__fmul_rn(d0, d0) + (double)__fmul_rn(d1, d1) + (double)__fmul_rn(d2, d2), sq_c = 0.0;
     composite_bwd_ray(ray, lane, Tsh, e.raw_l, e.C_l, e.z_l, e.rays_d, e.d_ld, e.noise_l, e.white_bkgd, e.S_l,
-                      __fmul_rn(scale, d0), __fmul_rn(scale, d1), __fmul_rn(scale, d2), e.d_raw_l);
+                      __fmul_rn(scale, d0), __fmul_rn(scale, d1), __fmul_rn(scale, d2), e.d_raw_l, e.dC_l > 0 ? e.dC_l : e.C_l);
     if (e.raw_c) {
         const float c0 = e.rgb_c[ray * 3 + 0], c1 = e.rgb_c[ray * 3 + 1], c2 = e.rgb_c[ray * 3 + 2];
         const float f0 = __fsub_rn(c0, t0), f1 = __fsub_rn(c1, t1), f2 = __fsub_rn(c2, t2);
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(64) void train_epilogue_kernel(const TrainEpilogue 
         if (lane < 3 && e.out_rgb0) e.out_rgb0[ray * 3 + lane] = e.rgb_c[ray * 3 + lane];
         __syncthreads();      // (Tsh is reused)
         composite_bwd_ray(ray, lane, Tsh, e.raw_c, e.C_c, e.z_c, e.rays_d, e.d_ld, e.noise_c, e.white_bkgd, e.S_c,
-                          __fmul_rn(scale, f0), __fmul_rn(scale, f1), __fmul_rn(scale, f2), e.d_raw_c);
+                          __fmul_rn(scale, f0), __fmul_rn(scale, f1), __fmul_rn(scale, f2), e.d_raw_c, e.dC_c > 0 ? e.dC_c : e.C_c);
     }
     // ---- the loss values: the last workgroup to arrive adds the rays' sums up ----
     if (lane == 0) {

@@ -1140,7 +1140,7 @@ def save_checkpoint(path, global_step, network_fn, network_fine, optimizer):
 def train_on_batch(H, W, K, batch_rays, target_s, optimizer, chunk=1024 * 32, ndc=True, near=0., far=1.,
                    use_viewdirs=False, network_fn=None, network_query_fn=None, N_samples=64, N_importance=0,
                    network_fine=None, perturb=0., raw_noise_std=0., white_bkgd=False, lindisp=False, pytest=False,
-                   apply_update=True, _packed_rays=None, **unused):
+                   apply_update=True, _packed_rays=None, _z_vals_fine=None, **unused):
     """One iteration of the reference's training loop body (nerf.ipynb:1258-1282) on the GPU:
     ``render(H, W, K, rays=batch_rays, retraw=True, **render_kwargs_train)``, ``img_loss =
     img2mse(rgb, target_s)`` (``+ img2mse(rgb0, target_s)``), ``loss.backward()``, ``optimizer.step()``.
@@ -1210,6 +1210,10 @@ def train_on_batch(H, W, K, batch_rays, target_s, optimizer, chunk=1024 * 32, nd
     rgb = torch.empty((N, 3), **o)
     rgb0 = torch.empty((N, 3), **o) if Si > 0 else None
     a.stats, a.rgb_map, a.rgb0 = stats.data_ptr(), rgb.data_ptr(), (rgb0.data_ptr() if Si > 0 else None)
+    if _z_vals_fine is not None and Si > 0:      # (parity tests: the fine pass at the reference's fine depths)
+        zin = _dev(_z_vals_fine, ctx).reshape(N, Sc + Si)
+        keep.append(zin)
+        a.z_vals_fine_in = zin.data_ptr()
     a.stream = ctx.stream().value
     check(ctx.lib.nerf_train_step(ctx.handle, C.byref(a)))
     out = {'img_loss': stats[0], 'psnr': stats[3], 'rgb': rgb, 'loss': stats[2]}

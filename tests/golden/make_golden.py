@@ -688,24 +688,42 @@ def gold_train_noviewdirs():
     8-column rays), coarse + fine, with the reference's pytest RNG: losses, gradient norms and every 61st element.
     views_linears.0.* exists in the module (nerf/nerf.py:43) and never receives a gradient."""
     g = np.load(os.path.join(HERE, "render_rays_lego.npz"))
-    rays = torch.from_numpy(g["rays"][:32, :8].copy())
-    target = torch.from_numpy(np.random.RandomState(106).uniform(0, 1, size=(32, 3)).astype(np.float32))
+    rays_np = g["rays"][:32, :8].copy()
+    target_np = np.random.RandomState(106).uniform(0, 1, size=(32, 3)).astype(np.float32)
     arch = dict(input_ch_views=0, use_viewdirs=False, output_ch=5)
-    net_c, net_f = ref_model(8, **arch), ref_model(48, **arch)
-    net_c.train(); net_f.train()
-    e_fn, _ = ref_embedder.get_embedder(10, 0)
-    kw = dict(N_samples=64, N_importance=128, retraw=True, white_bkgd=True, perturb=1.0, raw_noise_std=1.0, pytest=True)
-    r = NS["render_rays"](rays, net_c, query_fn(e_fn, None), network_fine=net_f, **kw)
-    img_loss, img_loss0 = ref_helpers.img2mse(r["rgb_map"], target), ref_helpers.img2mse(r["rgb0"], target)
-    (img_loss + img_loss0).backward()
-    out = dict(rays=n(rays), target=n(target), img_loss=n(img_loss), img_loss0=n(img_loss0), rgb=n(r["rgb_map"]),
+    out = dict(rays=rays_np, target=target_np,
                digest_c=synthetic.state_dict_digest(synthetic.synthetic_state_dict(8, **arch)),
                digest_f=synthetic.state_dict_digest(synthetic.synthetic_state_dict(48, **arch)))
-    for tag, net in (("c", net_c), ("f", net_f)):
-        for k, p in net.named_parameters():
-            gr = n(p.grad).reshape(-1) if p.grad is not None else np.zeros(p.numel(), np.float32)
-            out[f"gnorm_{tag}.{k}"] = np.linalg.norm(gr.astype(np.float64))
-            out[f"gsub_{tag}.{k}"] = gr[::61].copy()
+    # (round 4) the same iteration also in float64 (suffix .f64): with 32 rays one ray whose fine samples land in other bins
+    # moves a fine-network gradient by percents; the reference's own fp32-vs-fp64 distance is the yardstick, as in gold_train_scenes
+    for sfx, dtype in (("", torch.float32), (".f64", torch.float64)):
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            rays, target = torch.from_numpy(rays_np.copy()).to(dtype), torch.from_numpy(target_np).to(dtype)
+            net_c, net_f = ref_model(8, dtype, **arch), ref_model(48, dtype, **arch)
+            net_c.train(); net_f.train()
+            e_fn, _ = ref_embedder.get_embedder(10, 0)
+            kw = dict(N_samples=64, N_importance=128, retraw=True, white_bkgd=True, perturb=1.0, raw_noise_std=1.0, pytest=True)
+            recorded = []
+            orig_pdf = NS["sample_pdf"]
+            NS["sample_pdf"] = lambda *a, **k: (recorded.append(orig_pdf(*a, **k)) or recorded[-1])
+            try:
+                r = NS["render_rays"](rays, net_c, query_fn(e_fn, None), network_fine=net_f, **kw)
+            finally:
+                NS["sample_pdf"] = orig_pdf
+            img_loss, img_loss0 = ref_helpers.img2mse(r["rgb_map"], target), ref_helpers.img2mse(r["rgb0"], target)
+            (img_loss + img_loss0).backward()
+        finally:
+            torch.set_default_dtype(old)
+        out.update({"img_loss" + sfx: n(img_loss), "img_loss0" + sfx: n(img_loss0), "rgb" + sfx: n(r["rgb_map"])})
+        if sfx == "":      # the fp32 run's 128 new fine depths per ray: z_fine = sort(cat[z_coarse, z_samples]) (nerf.ipynb:467)
+            out["z_samples"] = n(recorded[0])
+        for tag, net in (("c", net_c), ("f", net_f)):
+            for k, p in net.named_parameters():
+                gr = n(p.grad).reshape(-1) if p.grad is not None else np.zeros(p.numel(), n(p).dtype)
+                out[f"gnorm_{tag}.{k}{sfx}"] = np.linalg.norm(gr.astype(np.float64))
+                out[f"gsub_{tag}.{k}{sfx}"] = gr[::61].copy()
     save("train_step_noviewdirs", **out)
 
 

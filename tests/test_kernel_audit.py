@@ -27,7 +27,9 @@ KERNELS = {
     # 32 points with nt stores)
     "mlp_kernel_h2.hip": (("kernelILi0ELi0E", "kernelILi1ELi0E", "kernelILi2ELi0E", "kernelILi2ELi1E", "kernelILi2ELi2E"), 1000, 400),
     # the training backward-data kernel on the same machinery, row-major and blocked
-    "mlp_bwd_kernel_h2.hip": (("nerf_mlp_bwd_h2_kernelILb0E", "nerf_mlp_bwd_h2_kernelILb1E"), 600, 300),
+    # (<blocked, view-dependent>: the chain without view directions is 12 chunks shorter)
+    "mlp_bwd_kernel_h2.hip": (("nerf_mlp_bwd_h2_kernelILb0ELb1E", "nerf_mlp_bwd_h2_kernelILb1ELb1E", "nerf_mlp_bwd_h2_kernelILb0ELb0E",
+                               "nerf_mlp_bwd_h2_kernelILb1ELb0E"), 400, 200),
 }
 
 

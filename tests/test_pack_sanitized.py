@@ -203,7 +203,14 @@ def repack(D, W, in_ch, in_v, out_ch, viewdirs, skips):
                 bias += row_tiles(outl, c, 8)
         n_out = out_ch
     if not viewdirs and W == 256 and out_ch <= 8 and D >= 2:
-        for i in range(D - 1, 0, -1):      # backward stream without a view branch: the trunk's transposes only
+        # backward stream without a view branch: W_output^T as one k-tile (columns 0..C-1: d h_{D-1} = W_output^T d raw on the
+        # matrix pipe, round 4), then the trunk's transposes
+        class HeadT:
+            @staticmethod
+            def at(r, c):
+                return outl.w[c, r] if (r < W and 0 <= c < out_ch) else 0.0
+        bwd.append(chunk_ktile(HeadT, 8, lambda t, h: hidden_col(0, t, h)))
+        for i in range(D - 1, 0, -1):
             for kt in range(8):
                 bwd.append(chunk_ktile(LinT(lins[i], W, W, in_ch if (mask >> i) & 1 else 0), 8,
                                        lambda t, h, kt=kt: hidden_col(kt, t, h)))
