@@ -354,11 +354,12 @@ struct GemmTN {        // part[slice][Mo, No] = sum_p A[p,Mo]^T B[p,No];  dbp[sl
     float* dbp;
     int narrow_first;   // the columns beyond a multiple of 256 come first (cat[gamma(x), h]) rather than last
     GradExps ex;        // see GradJob
+    int b_blocked;      // gemm_tn_small4_kernel only: B (X, 256 wide) is blocked by 32 points (MlpStore::blocked); ldb unused
 };
 hipError_t launch_gemm_rows(const GemmRows& g, hipStream_t s);
 hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, float* db, int accumulate, hipStream_t s);
 int gemm_tn_col_blocks(int Mo, int No);
-bool gemm_tn_is_small(int Mo);
+bool gemm_tn_is_small(int Mo, int No);
 bool gemm_tn_is_direct(int Mo);
 // Several weight gradients in ONE launch (train_dw_kernel.hip): a job = the columns [n_begin, n_end) of one Linear's
 // dW = dY^T X (+ db), Mo a multiple of 128. All jobs of a batch share the point range and its split into slices, so

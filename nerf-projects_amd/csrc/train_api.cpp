@@ -511,7 +511,7 @@ struct TnScratch {
 // Slices per GEMM: the grid is slices x column blocks (gemm_tn_col_blocks) workgroups at one per CU, so aim at a whole number of
 // 256-workgroup rounds (a 1.5-round grid wastes a third of the machine) while keeping >= 256 points per slice.
 inline int pick_slices(int64_t P, int Mo, int No, int max_slices) {
-    if (gemm_tn_is_small(Mo)) {     // [slices][Mo <= 4][No] partials: 2048 slices fit the buffers sized for 256 x 256 rows
+    if (gemm_tn_is_small(Mo, No)) {     // [slices][Mo <= 8][No] partials: 2048 slices fit the buffers sized for 256 x 256 rows
         const int64_t s = (P + 63) / 64;      // (measured with 128 / 256 / 512 points per slice: 48 / 55 / 88 us per launch against 42)
         return (int)(s < 1 ? 1 : (s > 2048 ? 2048 : s));
     }
@@ -539,7 +539,7 @@ GradExps grad_exps(const PackedNet& net, int k, bool eq) {
 
 // dW (+db) of one Linear: dW = dY^T X, db = dY^T 1
 int grad_linear(const PackedNet& net, const LinearDesc& d, const float* dY, int ldy, const float* X, int ldx, int64_t P,
-                const TnScratch& sc, hipStream_t s, bool eq = false) {
+                const TnScratch& sc, hipStream_t s, bool eq = false, bool x_blocked = false) {
     const int n_slices = pick_slices(P, d.out, d.in, sc.max_slices);
     int64_t pps = (P + n_slices - 1) / n_slices;
     pps = (pps + kSlicePointQuantum - 1) / kSlicePointQuantum * kSlicePointQuantum;
@@ -547,7 +547,7 @@ int grad_linear(const PackedNet& net, const LinearDesc& d, const float* dY, int 
     // reads cat[feature, gamma(d)] (nerf.py:93): last
     const bool trunk = &d >= &net.linears[0] && &d < &net.linears[0] + net.arch.D;
     GemmTN g{dY, ldy, X, ldx, P, d.out, d.in, pps, sc.part, sc.dbp, (trunk && d.in > net.arch.W) ? 1 : 0,
-             grad_exps(net, (int)(&d - &net.linears[0]), eq)};
+             grad_exps(net, (int)(&d - &net.linears[0]), eq), x_blocked ? 1 : 0};
     HIP_TRY(launch_gemm_tn(g, n_slices, net.train.d_grad + d.w_off, d.in, net.train.d_grad + d.b_off, sc.accumulate, s));
     return NERF_OK;
 }
@@ -566,6 +566,34 @@ bool gemm_backward_requested() {
 }
 
 int backward_pass_fused_noviews(Pass& ps, const TnScratch& sc, hipStream_t s);
+
+// NERF_TRAIN_NARROW=f32: the gamma(x) / gamma(d) columns' weight gradients of a blocked pass on the fp32 kernel (A/B)
+bool narrow_pair_wanted() {
+    static const bool on = [] {
+        const char* e = getenv("NERF_TRAIN_NARROW");
+        return !(e && (e[0] == 'f' || e[0] == 'F') && e[1] == '3');
+    }();
+    return on;
+}
+
+// The gamma columns' jobs on the fp16 pipe (grad_batch_narrow_pair_kernel). A workgroup is a slice (its four waves share its
+// points and add their sums up in LDS): as many as fill the chip's 256 workgroups once over all jobs
+int narrow_pair_batch(Pass& ps, const TnScratch& sc, GradBatch& narrow_pair, hipStream_t s) {
+    if (narrow_pair.n == 0) return NERF_OK;
+    int n_slices = 256 / narrow_pair.n;
+    const int64_t cap = (ps.P + 255) / 256;
+    if (n_slices > cap) n_slices = (int)cap;
+    if (n_slices < 1) n_slices = 1;
+    int64_t pps = (ps.P + n_slices - 1) / n_slices;
+    pps = (pps + 127) / 128 * 128;
+    narrow_pair.n_slices = n_slices;
+    narrow_pair.pts_per_slice = pps;
+    narrow_pair.P = ps.P;
+    narrow_pair.accumulate = sc.accumulate;
+    TrainTimer timer(ps.ctx, s, 3, ps.P);
+    HIP_TRY(launch_grad_batch_narrow_pair(narrow_pair, sc.part, sc.part_floats, sc.dbp, sc.dbp_floats, s));
+    return NERF_OK;
+}
 
 int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
     const PackedNet& net = *ps.net;
@@ -671,12 +699,8 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
         // every hidden-width operand blocked by 32 points, in a buffer of its own; the gamma(x) / gamma(d) columns' jobs read
         // a blocked dY against a narrow row-major X (rows of 64, zero-padded) whose column 0 is column n_begin of the Linear's
         // input: on the fp16 pipe too (grad_batch_narrow_pair_kernel), or - NERF_TRAIN_NARROW=f32 - on the fp32 one
-        static const bool narrow_pair_wanted = [] {
-            const char* e = getenv("NERF_TRAIN_NARROW");
-            return !(e && (e[0] == 'f' || e[0] == 'F') && e[1] == '3');
-        }();
-        GradBatch& nb = narrow_pair_wanted ? narrow_pair : narrow;
-        const int np = narrow_pair_wanted ? 1 : 0;
+        GradBatch& nb = narrow_pair_wanted() ? narrow_pair : narrow;
+        const int np = narrow_pair_wanted() ? 1 : 0;
         job(pairs, feat, d_feat, a.W, ps.h[a.D - 1], a.W, 0, a.W, true, mx(kBwdMaxFeat), mx(kBwdMaxKept + a.D - 1), 3, 0);
         job(pairs, views, ps.g_hv, views.out, ps.feat_blk, a.W, 0, a.W, true, mx(kBwdMaxViews), mx(kBwdMaxFeatValue), 3, 0);
         if (views.in > a.W)
@@ -730,23 +754,7 @@ int backward_pass_fused(Pass& ps, const TnScratch& sc, hipStream_t s) {
             HIP_TRY(launch_grad_batch(*b, b != &narrow, sc.part, sc.part_floats, sc.dbp, sc.dbp_floats, s, b == &pairs));
         }
     }
-    if (narrow_pair.n > 0) {
-        // a workgroup is a slice (its four waves share its points and add their sums up in LDS): as many as fill the chip's 256
-        // workgroups once over all jobs
-        int n_slices = 256 / narrow_pair.n;
-        const int64_t cap = (ps.P + 255) / 256;
-        if (n_slices > cap) n_slices = (int)cap;
-        if (n_slices < 1) n_slices = 1;
-        int64_t pps = (ps.P + n_slices - 1) / n_slices;
-        pps = (pps + 127) / 128 * 128;
-        narrow_pair.n_slices = n_slices;
-        narrow_pair.pts_per_slice = pps;
-        narrow_pair.P = ps.P;
-        narrow_pair.accumulate = sc.accumulate;
-        TrainTimer timer(ps.ctx, s, 3, ps.P);
-        HIP_TRY(launch_grad_batch_narrow_pair(narrow_pair, sc.part, sc.part_floats, sc.dbp, sc.dbp_floats, s));
-    }
-    return NERF_OK;
+    return narrow_pair_batch(ps, sc, narrow_pair, s);
 }
 
 // Networks without view directions (use_viewdirs=False: output_linear on the trunk, nerf.py:109): the same fused fp32 launch
@@ -779,6 +787,7 @@ int backward_pass_fused_noviews(Pass& ps, const TnScratch& sc, hipStream_t s) {
         b.out.h[i] = ps.dz[i];
         b.out.h_ld[i] = a.W;
     }
+    b.out.blocked = ps.blocked ? 1 : 0;
     const bool pair_dw = ps.precision == NERF_PRECISION_F16X2 && pair_dw_allowed() && ps.maxes != nullptr;
     if (pair_dw || ps.pair_backward) b.maxes = ps.maxes;
     if (ps.pair_backward) {
@@ -795,21 +804,43 @@ int backward_pass_fused_noviews(Pass& ps, const TnScratch& sc, hipStream_t s) {
         HIP_TRY(launch_mlp_bwd(b, s));
     }
     int rc;
-    if ((rc = grad_linear(net, out, ps.d_raw, ps.dC, ps.h[a.D - 1], ps.h_ld[a.D - 1], ps.P, sc, s, eq))) return rc;
+    if (ps.blocked && !(pair_dw && ps.pair_backward && a.input_ch <= 64 && a.D <= kMaxGradJobs && gemm_tn_is_small(out.out, a.W))) {
+        set_error("internal: the blocked activation layout was chosen for a pass whose weight gradients cannot read it");
+        return NERF_E_INVALID;
+    }
+    if ((rc = grad_linear(net, out, ps.d_raw, ps.dC, ps.h[a.D - 1], ps.h_ld[a.D - 1], ps.P, sc, s, eq, ps.blocked))) return rc;
     if (!sc.accumulate)
         HIP_TRY(hipMemsetAsync(net.train.d_grad + views.w_off, 0, ((size_t)views.out * views.in + views.out) * sizeof(float), s));
     float* grad = net.train.d_grad;
-    GradBatch wide{}, narrow{}, pairs{};
+    GradBatch wide{}, narrow{}, pairs{}, narrow_pair{};
     auto job = [&](GradBatch& bt, const LinearDesc& d, const float* dY, const float* X, int ldx, int n0, int n1, bool with_db,
-                   const unsigned* a_max = nullptr, const unsigned* b_max = nullptr) {
-        bt.job[bt.n++] = GradJob{dY, a.W, X, ldx, d.out, n0, n1, grad + d.w_off, d.in, with_db ? grad + d.b_off : nullptr,
-                                 nullptr, nullptr, a_max, b_max, grad_exps(net, (int)(&d - &net.linears[0]), eq)};
+                   const unsigned* a_max = nullptr, const unsigned* b_max = nullptr, int blocked = 0, int b_first = 0) {
+        GradJob& j = bt.job[bt.n++];
+        j = GradJob{dY, a.W, X, ldx, d.out, n0, n1, grad + d.w_off, d.in, with_db ? grad + d.b_off : nullptr,
+                    nullptr, nullptr, a_max, b_max, grad_exps(net, (int)(&d - &net.linears[0]), eq)};
+        j.blocked = blocked;
+        j.b_first = b_first;
     };
-    if (a.input_ch > 64 || a.D > kMaxGradJobs) {
+    if (ps.blocked) {
+        // as backward_pass_fused: hidden-width operands blocked by 32 points, the gamma(x) columns' jobs a blocked dY against the
+        // narrow row-major gamma(x) (rows of 64, zero-padded)
+        GradBatch& nb = narrow_pair_wanted() ? narrow_pair : narrow;
+        for (int i = a.D - 1; i >= 0; --i) {
+            const LinearDesc& d = net.linears[i];
+            if (d.in >= a.W) {
+                const int lead = d.in - a.W;
+                job(pairs, d, ps.dz[i], ps.h[i - 1], a.W, lead, d.in, true, ps.maxes + i, ps.maxes + kBwdMaxKept + i - 1, 3, lead);
+                if (lead > 0) job(nb, d, ps.dz[i], ps.in[i], ps.in_ld[i], 0, lead, false, ps.maxes + i, ps.maxes + kBwdMaxGammaX, 1);
+            } else {
+                job(nb, d, ps.dz[i], ps.in[i], ps.in_ld[i], 0, d.in, true, ps.maxes + i, ps.maxes + kBwdMaxGammaX, 1);
+            }
+        }
+    } else if (a.input_ch > 64 || a.D > kMaxGradJobs) {
         for (int i = a.D - 1; i >= 0; --i)
             if ((rc = grad_linear(net, net.linears[i], ps.dz[i], a.W, ps.in[i], ps.in_ld[i], ps.P, sc, s, eq))) return rc;
         return NERF_OK;
     }
+    if (!ps.blocked) {
     GradBatch& hidden = pair_dw ? pairs : wide;
     for (int i = a.D - 1; i >= 0; --i) {
         const LinearDesc& d = net.linears[i];
@@ -821,6 +852,7 @@ int backward_pass_fused_noviews(Pass& ps, const TnScratch& sc, hipStream_t s) {
         } else {
             job(narrow, d, ps.dz[i], ps.in[i], ps.in_ld[i], 0, d.in, true);            // layer 0: gamma(x) only
         }
+    }
     }
     for (GradBatch* bt : {&pairs, &wide, &narrow}) {
         if (bt->n == 0) continue;
@@ -837,7 +869,7 @@ int backward_pass_fused_noviews(Pass& ps, const TnScratch& sc, hipStream_t s) {
         TrainTimer timer(ps.ctx, s, bt == &narrow ? 3 : 2, ps.P);
         HIP_TRY(launch_grad_batch(*bt, bt != &narrow, sc.part, sc.part_floats, sc.dbp, sc.dbp_floats, s, bt == &pairs));
     }
-    return NERF_OK;
+    return narrow_pair_batch(ps, sc, narrow_pair, s);
 }
 
 int backward_pass(Pass& ps, const TnScratch& sc, hipStream_t s) {
@@ -925,9 +957,12 @@ void set_units(Pass& ps) {
         const char* e = getenv("NERF_TRAIN_DW_RIDER");
         return !(e && *e == '0');
     }();
-    ps.blocked = blocked_wanted && ps.pair_backward && pair_dw_allowed() && rider_on && grad_pair_takes_riders() &&
-                 gemm_tn_is_direct(a.W) && gemm_tn_is_direct(a.W / 2) && a.input_ch <= 64 && a.input_ch_views <= 64 &&
-                 a.D + 2 <= kMaxGradJobs && a.use_viewdirs && ps.net->out_ch == 4 && (uint64_t)ps.P * 1024u < ((uint64_t)1 << 32);
+    const bool dw_reads_blocked =
+        a.use_viewdirs ? rider_on && grad_pair_takes_riders() && gemm_tn_is_direct(a.W / 2) && a.input_ch_views <= 64 &&
+                             a.D + 2 <= kMaxGradJobs && ps.net->out_ch == 4
+                       : a.D <= kMaxGradJobs && gemm_tn_is_small(ps.net->out_ch, a.W);      // (backward_pass_fused_noviews)
+    ps.blocked = blocked_wanted && ps.pair_backward && pair_dw_allowed() && gemm_tn_is_direct(a.W) && a.input_ch <= 64 &&
+                 dw_reads_blocked && (uint64_t)ps.P * 1024u < ((uint64_t)1 << 32);
 }
 
 }  // namespace

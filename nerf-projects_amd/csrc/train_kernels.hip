@@ -486,43 +486,53 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(GemmTN g) {
 // takes FOUR columns, so a wave's load instruction moves a KiB instead of 256 bytes and the No / 4 threads of a point leave
 // room in the workgroup for 256 / (No / 4) points side by side (their sums are added through LDS, in order).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+// MM: rows held per thread (4: rgb_linear, alpha_linear; 8: an output_linear of up to 8 channels). g.b_blocked: X is blocked by 32
+// points (MlpStore::blocked; No = 256): the four features 4 i .. 4 i + 3 of point p sit in piece i / 2 of p's group.
+template <int MM>
 __global__ __launch_bounds__(256) void gemm_tn_small4_kernel(GemmTN g) {
-    __shared__ float red[4 * 1024];            // [point lane][m][column]: 256 / (No / 4) x 4 x No floats
-    __shared__ float redb[16][4];
+    __shared__ float red[MM * 1024];           // [point lane][m][column]: 256 / (No / 4) x MM x No floats
+    __shared__ float redb[16][MM];
     const int tpp = g.No >> 2;                 // threads per point: 64, 32 or 16
     const int pl = threadIdx.x / tpp, c = 4 * (threadIdx.x % tpp), n_pl = 256 / tpp;
     const int slice = blockIdx.x;
     const int64_t p_begin = (int64_t)slice * g.pts_per_slice;
     int64_t p_end = p_begin + g.pts_per_slice;
     if (p_end > g.P) p_end = g.P;
-    f32x4v acc[4];
-    float bsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto x_at = [&](int64_t p) -> const float* {
+        return g.b_blocked ? g.B + (p >> 5) * (32 * (int64_t)256) + (c >> 3) * 256 + (int)(p & 31) * 8 + ((c >> 2) & 1) * 4
+                           : g.B + p * g.ldb + c;
+    };
+    f32x4v acc[MM];
+    float bsum[MM];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int m = 0; m < MM; ++m) {
+        acc[m] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        bsum[m] = 0.0f;
+    }
     int64_t p = p_begin + pl;
     const int64_t step = n_pl;
     for (; p + 3 * step < p_end; p += 4 * step) {
         f32x4v x[4];
-        float a[4][4];
+        float a[4][MM];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            x[u] = *(const f32x4v*)(g.B + (p + u * step) * g.ldb + c);
+            x[u] = *(const f32x4v*)x_at(p + u * step);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) a[u][m] = g.A[(p + u * step) * g.lda + (m < g.Mo ? m : 0)];
+            for (int m = 0; m < MM; ++m) a[u][m] = g.A[(p + u * step) * g.lda + (m < g.Mo ? m : 0)];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MM; ++m) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[m][q] = fmaf(a[u][m], x[u][q], acc[m][q]);
                 bsum[m] += a[u][m];
             }
     }
     for (; p < p_end; p += step) {
-        const f32x4v x = *(const f32x4v*)(g.B + p * g.ldb + c);
+        const f32x4v x = *(const f32x4v*)x_at(p);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MM; ++m) {
             const float a = g.A[p * g.lda + (m < g.Mo ? m : 0)];
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[m][q] = fmaf(a, x[q], acc[m][q]);
@@ -530,15 +540,15 @@ __global__ __launch_bounds__(256) void gemm_tn_small4_kernel(GemmTN g) {
         }
     }
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        *(f32x4v*)&red[(pl * 4 + m) * g.No + c] = acc[m];
+    for (int m = 0; m < MM; ++m) {
+        *(f32x4v*)&red[(pl * MM + m) * g.No + c] = acc[m];
         if (c == 0) redb[pl][m] = bsum[m];
     }
     __syncthreads();
     for (int e = threadIdx.x; e < g.Mo * g.No; e += 256) {
         const int m = e / g.No, n = e % g.No;
         float t = red[m * g.No + n];
-        for (int q = 1; q < n_pl; ++q) t += red[(q * 4 + m) * g.No + n];
+        for (int q = 1; q < n_pl; ++q) t += red[(q * MM + m) * g.No + n];
         g.part[((int64_t)slice * g.Mo + m) * g.No + n] = t;
     }
     if (g.dbp && threadIdx.x < g.Mo) {
@@ -559,10 +569,13 @@ static bool staged_dw_requested() {
 
 // workgroups per slice of the launch that does the bulk of a layer's dW (the caller sizes the number of slices with it)
 // the weighted-column-sum kernel wants many short slices (its only parallelism besides the columns)
-bool gemm_tn_is_small(int Mo) { return Mo <= 4 && !staged_dw_requested(); }
+// (five to eight rows - an output_linear of more than four channels - only against an X the 16-byte kernel reads)
+bool gemm_tn_is_small(int Mo, int No) {
+    return (Mo <= 4 || (Mo <= 8 && (No == 256 || No == 128 || No == 64))) && !staged_dw_requested();
+}
 
 int gemm_tn_col_blocks(int Mo, int No) {
-    if (gemm_tn_is_small(Mo)) return (No + 255) / 256;
+    if (gemm_tn_is_small(Mo, No)) return (No + 255) / 256;
     if (Mo % 128 == 0 && Mo <= 256 && !staged_dw_requested()) return 1;
     return (No + 127) / 128;
 }
@@ -605,12 +618,18 @@ hipError_t launch_gemm_tn(const GemmTN& g, int n_slices, float* dW, int ldw, flo
         }
         return hipSuccess;
     }
-    if (gemm_tn_is_small(g.Mo)) {
-        const bool by_four = (g.No == 256 || g.No == 128 || g.No == 64) && g.ldb % 4 == 0 && ((uintptr_t)g.B & 15) == 0;
-        if (by_four)
-            hipLaunchKernelGGL(gemm_tn_small4_kernel, dim3((unsigned)n_slices), dim3(256), 0, s, g);
-        else
+    if (gemm_tn_is_small(g.Mo, g.No)) {
+        const bool by_four = (g.No == 256 || g.No == 128 || g.No == 64) && ((uintptr_t)g.B & 15) == 0 &&
+                             (g.b_blocked ? g.No == 256 : g.ldb % 4 == 0);
+        if (g.b_blocked && !by_four) return hipErrorInvalidValue;
+        if (by_four && g.Mo <= 4)
+            hipLaunchKernelGGL(gemm_tn_small4_kernel<4>, dim3((unsigned)n_slices), dim3(256), 0, s, g);
+        else if (by_four)
+            hipLaunchKernelGGL(gemm_tn_small4_kernel<8>, dim3((unsigned)n_slices), dim3(256), 0, s, g);
+        else if (g.Mo <= 4)
             hipLaunchKernelGGL(gemm_tn_small_kernel, dim3((unsigned)n_slices, (unsigned)((g.No + 255) / 256)), dim3(256), 0, s, g);
+        else
+            return hipErrorInvalidValue;      // (more than four rows against an X that is not 16-byte aligned: no caller has one)
         const int64_t n_all = (int64_t)g.Mo * g.No + g.Mo;
         hipLaunchKernelGGL(reduce_many_slices_kernel, dim3((unsigned)((n_all + 15) / 16)), dim3(256), 0, s, g.part, g.dbp,
                            n_slices, g.Mo, g.No, dW, ldw, db, accumulate, g.ex);

@@ -1472,15 +1472,20 @@ import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
 import nerf_projects_amd as N
 from nerf_projects_amd import synthetic
-out_path, precision, n_imp = sys.argv[2], sys.argv[3], int(sys.argv[4])
+out_path, precision, n_imp, views = sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5] == "views"
 ctx = N.get_context(); ctx.set_precision(precision)
 g = np.load(sys.argv[1] + "/tests/golden/train_step.npz")
-sd_c, sd_f = synthetic.synthetic_pair(0)
-mk = dict(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True)
+if views:
+    sd_c, sd_f = synthetic.synthetic_pair(0)
+    mk = dict(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True)
+else:      # nerf.ipynb:879-885: no view directions, a 5-channel output_linear
+    arch = dict(input_ch_views=0, use_viewdirs=False, output_ch=5)
+    sd_c, sd_f = synthetic.synthetic_state_dict(8, **arch), synthetic.synthetic_state_dict(48, **arch)
+    mk = dict(D=8, W=256, input_ch=63, skips=[4], **arch)
 net_c, net_f = N.NeRF(**mk).load_state_dict(sd_c), N.NeRF(**mk).load_state_dict(sd_f)
 opt = N.Adam([net_c, net_f], lr=5e-4)
 kw = dict(network_fn=net_c, network_fine=net_f if n_imp else None, N_samples=64, N_importance=n_imp, white_bkgd=True, perturb=1.0,
-          raw_noise_std=1.0, pytest=True, ndc=False, use_viewdirs=True, near=2., far=6.)
+          raw_noise_std=1.0, pytest=True, ndc=False, use_viewdirs=views, near=2., far=6.)
 rays = torch.from_numpy(g["rays"]).cuda()
 res = {}
 for it in range(2):
@@ -1499,9 +1504,11 @@ np.savez(out_path, **res)
 """
 
 
-@pytest.mark.parametrize("n_imp,switch", [(128, "NERF_TRAIN_GLUE=legacy"), (0, "NERF_TRAIN_GLUE=legacy"),
-                                          (128, "NERF_TRAIN_NARROW=f32 NERF_TRAIN_BLOCKED=0")])
-def test_train_glue_is_bit_identical(N, n_imp, switch, tmp_path):
+@pytest.mark.parametrize("n_imp,switch,views", [(128, "NERF_TRAIN_GLUE=legacy", "views"), (0, "NERF_TRAIN_GLUE=legacy", "views"),
+                                                (128, "NERF_TRAIN_NARROW=f32 NERF_TRAIN_BLOCKED=0", "views"),
+                                                (128, "NERF_TRAIN_GLUE=legacy", "noviews"),
+                                                (128, "NERF_TRAIN_NARROW=f32 NERF_TRAIN_BLOCKED=0", "noviews")])
+def test_train_glue_is_bit_identical(N, n_imp, switch, views, tmp_path):
     """Two optimiser steps on the reference's fixture batch, twice: as shipped, and with one of the step's A/B switches thrown
     (each needs a process of its own: the switches are read once) - every loss, PSNR, colour, gradient and weight bit for bit.
     NERF_TRAIN_GLUE=legacy: the step's small stages as the stage kernels they were (stratified depths, encodings, raw2outputs,
@@ -1509,7 +1516,7 @@ def test_train_glue_is_bit_identical(N, n_imp, switch, tmp_path):
     (prologue / mid / epilogue / two refresh launches). NERF_TRAIN_BLOCKED=0: the kept activations and pre-activation gradients
     row-major instead of blocked by 32 points - the same values in the same registers of the same kernels (both runs with the
     gamma columns' weight gradients on the fp32 pipe, NERF_TRAIN_NARROW=f32: their fp16-pipe kernel exists for the blocked
-    layout only)."""
+    layout only). "noviews": the same for a pair of networks without view directions (a 5-channel output_linear on the trunk)."""
     import subprocess
     import sys
     import os
@@ -1524,7 +1531,7 @@ def test_train_glue_is_bit_identical(N, n_imp, switch, tmp_path):
         for var, value in (sets if mode == "switched" else sets[:-1]):
             env[var] = value
         path = str(tmp_path / f"{mode}.npz")
-        subprocess.run([sys.executable, "-c", _GLUE_RUN, root, path, precision, str(n_imp)], check=True, env=env, timeout=600)
+        subprocess.run([sys.executable, "-c", _GLUE_RUN, root, path, precision, str(n_imp), views], check=True, env=env, timeout=600)
         results[mode] = np.load(path)
     a, b = results["shipped"], results["switched"]
     assert sorted(a.files) == sorted(b.files) and len(a.files) > 50
