@@ -452,6 +452,10 @@ __device__ __forceinline__ void keep_quad(float* base, unsigned off, const f32x4
 // the same with the nt bit, for stores that write whole lines of data nobody reads soon (the layout blocked by 32 points)
 template <int IMM>
 __device__ __forceinline__ void keep_quad_nt(float* base, unsigned off, const f32x4& v) {
+#ifdef NERF_EXP_NOSTORE      // timing experiments (profiles/r04_ab_notes.txt)
+    asm volatile("" ::"v"(v), "v"(off), "s"(base));
+    return;
+#endif
     asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base), "n"(IMM) : "memory");
 }
 template <int IMM>
