@@ -365,6 +365,31 @@ __device__ __forceinline__ void dma_read_set(PairSet& r, unsigned addr) {
     }
 }
 
+// A step's operands split into fp16 (hi, lo) fragments: what its 48 MFMAs read
+struct PairConv {
+    u32x4 ahi[4], alo[4], bhi[4], blo[4];
+};
+// unit u of the sixteen a step's split is made of: feature t = u / 4 of the point pairs (2 q, 2 q + 1), q = u % 4, both operands
+__device__ __forceinline__ void pair_convert_unit(PairConv& c, const PairSet& r, int u, float sa, float sb, float (&asum)[4]) {
+    const int t = u >> 2, q = u & 3;
+    const float a0 = r.a[2 * q][t], a1 = r.a[2 * q + 1][t];
+    asum[t] += a0 + a1;
+    unsigned hi, lo;
+    pair_split(a0 * sa, a1 * sa, hi, lo);
+    c.ahi[t][q] = hi;
+    c.alo[t][q] = lo;
+    pair_split(r.b[2 * q][t] * sb, r.b[2 * q + 1][t] * sb, hi, lo);
+    c.bhi[t][q] = hi;
+    c.blo[t][q] = lo;
+}
+// accumulator tile g = 4 tm + tn of the wave's sixteen: its three products, smallest first
+__device__ __forceinline__ void pair_mma_tile(f32x16 (&acc)[4][4], const PairConv& c, int g) {
+    const int tm = g >> 2, tn = g & 3;
+    acc[tm][tn] = mfma16h(c.alo[tm], c.bhi[tn], acc[tm][tn]);
+    acc[tm][tn] = mfma16h(c.ahi[tm], c.blo[tn], acc[tm][tn]);
+    acc[tm][tn] = mfma16h(c.ahi[tm], c.bhi[tn], acc[tm][tn]);
+}
+
 template <bool BLK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void grad_batch_pair_dma_kernel(const GradBatch b) {
@@ -421,18 +446,21 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
     // pieces 8..15, this lane's point octet (8 kh) and half-wave (i % 2)
     const unsigned my_addr = BLK ? my_lds + ((i >> 1) & 7) * kDmaImage + (i >> 4) * 512 + kh * 256 + (i & 1) * 16 : my_lds + lane * 16;
 
-    auto issue = [&](int slot) {      // the sixteen loads of the step at (pa, pb) into `slot`
+    // load u of the sixteen of the step at (pa, pb) into `slot`: a's eight in the order the old loop issued them pairwise with b's
+    auto issue_one = [&](int slot, int u) {
         char* base = my + slot * kDmaSlotBytes;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        const int j = u >> 1;
+        if ((u & 1) == 0)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + j * load_a),
                                              (__attribute__((address_space(3))) void*)(base + j * kDmaImage), 16, 0, 0);
+        else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + j * load_b),
                                              (__attribute__((address_space(3))) void*)(base + 8 * kDmaImage + j * kDmaImage), 16, 0, 0);
-        }
+    };
+    auto issue_done = [&](int slot) {      // behind the sixteen: the rider's load, the pointers on to the next step
         if (has_y) {      // lane l fetches y of point (l & 15) of the step: LDS [16 floats] x 4 copies
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)py,
-                                             (__attribute__((address_space(3))) void*)(base + kDmaRiderOff), 4, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(my + slot * kDmaSlotBytes + kDmaRiderOff), 4, 0, 0);
             py += step_y;
         }
         if constexpr (BLK) {
@@ -443,6 +471,11 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
             pa += step_a;
             pb += step_b;
         }
+    };
+    auto issue = [&](int slot) {      // the sixteen loads of the step at (pa, pb) into `slot`
+#pragma unroll
+        for (int u = 0; u < 16; ++u) issue_one(slot, u);
+        issue_done(slot);
     };
     auto ride = [&](const PairSet& r, const f32x4u& y0, const f32x4u& y1) {      // y of this lane's eight points
         typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -484,29 +517,100 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
             }
     };
 
-    for (int t = 0; t < kDmaSlots && t < n_steps; ++t) issue(t);
-    int slot = 0;
-    for (int s = 0; s < n_steps; ++s) {
-        __builtin_amdgcn_sched_barrier(0);
-        // step s has landed when at most the loads of the steps issued after it are outstanding
-        if (s + 1 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // A step = 48 MFMAs (1 536 matrix-pipe cycles) + its preparation: sixteen reads back from LDS, sixteen loads of the step two
+    // ahead into the slot just read, ~240 vector instructions of scaling and (hi, lo) splitting. One after the other - what hipcc
+    // makes of a loop body written that way, with one wave per SIMD and nobody else to issue - a step took ~4 000 cycles and the
+    // matrix pipe was busy 38 % of them (profiles/r04_train_pmc_summary.md, round 4): the kernel ran at 4.8 TB/s without being
+    // bound by memory. So the loop is software-pipelined by hand: while step s's MFMAs run from one register set (PairConv), step
+    // s + 1 is awaited, read back and split into the other, a slice of that work behind every accumulator tile's three MFMAs,
+    // the slices fenced (sched_barrier) so that they stay where they are put. Same products into the same accumulators in the
+    // same order: bit-identical sums.
+    // wait: step k has landed when at most the loads of the step issued after it are outstanding
+    auto await = [&](bool newer_in_flight) {
+        if (!newer_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (has_y) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");      // (a step of a wave with the rider is 17 loads)
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        PairSet r;
-        f32x4u y0 = {0.0f, 0.0f, 0.0f, 0.0f}, y1 = y0;
+    };
+    auto read_back = [&](PairSet& r, f32x4u& y0, f32x4u& y1, int slot) {
         dma_read_set<0, BLK>(r, my_addr + slot * kDmaSlotBytes);
         if (has_y) {
             const unsigned ya = my_lds + slot * kDmaSlotBytes + kh * 32;
             dma_read<kDmaRiderOff>(y0, ya);
             dma_read<kDmaRiderOff + 16>(y1, ya);
         }
+    };
+    // one step's preparation in the open (the first step, the last three): `more` = the step two ahead exists
+    auto prepare = [&](PairConv& c, int slot, bool newer_in_flight, bool more) {
+        __builtin_amdgcn_sched_barrier(0);
+        await(newer_in_flight);
+        PairSet r;
+        f32x4u y0 = {0.0f, 0.0f, 0.0f, 0.0f}, y1 = y0;
+        read_back(r, y0, y1, slot);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (read back: the slot may be overwritten)
         __builtin_amdgcn_sched_barrier(0);
-        if (s + kDmaSlots < n_steps) issue(slot);
+        if (more) issue(slot);
         __builtin_amdgcn_sched_barrier(0);
         if (has_y) ride(r, y0, y1);
-        step(r);
-        slot = slot + 1 == kDmaSlots ? 0 : slot + 1;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) pair_convert_unit(c, r, u, sa, sb, asum);
+    };
+    auto mma_all = [&](const PairConv& c) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) pair_mma_tile(acc, c, g);
+    };
+    // the steady state: step s's MFMAs from `cur`; step s + 1 (in `slot`, step s + 2 in flight behind it) into `nxt`; the loads
+    // of step s + 3 into `slot`
+    auto overlap = [&](const PairConv& cur, PairConv& nxt, int slot) {
+        __builtin_amdgcn_sched_barrier(0);
+        await(true);
+        PairSet r;
+        f32x4u y0 = {0.0f, 0.0f, 0.0f, 0.0f}, y1 = y0;
+        read_back(r, y0, y1, slot);
+        pair_mma_tile(acc, cur, 0);      // (two tiles' MFMAs cover the reads' latency)
+        pair_mma_tile(acc, cur, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_y) ride(r, y0, y1);
+#pragma unroll
+        for (int g = 2; g < 16; ++g) {
+            pair_mma_tile(acc, cur, g);
+            // sixteen units of splitting and sixteen loads behind fourteen tiles: two each behind the first two
+            const int u0 = g < 4 ? 2 * (g - 2) : g, n_u = g < 4 ? 2 : 1;
+#pragma unroll
+            for (int k = 0; k < n_u; ++k) {
+                pair_convert_unit(nxt, r, u0 + k, sa, sb, asum);
+                issue_one(slot, u0 + k);
+            }
+            if (g == 15) issue_done(slot);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (n_steps > 0) {
+        PairConv c0, c1;
+        issue(0);
+        if (n_steps > 1) issue(1);
+        prepare(c0, 0, n_steps > 1, n_steps > 2);
+        int s = 0;
+        // here: step s split in c0, steps s + 1 and s + 2 in flight (slots 1 and 0); a pass through the body issues s + 3 and s + 4
+        for (; s + 4 < n_steps; s += 2) {
+            overlap(c0, c1, 1);
+            overlap(c1, c0, 0);
+        }
+        // the last four steps or fewer, one thing after the other
+        mma_all(c0);
+        if (s + 1 < n_steps) {
+            prepare(c1, 1, s + 2 < n_steps, s + 3 < n_steps);
+            mma_all(c1);
+        }
+        if (s + 2 < n_steps) {
+            prepare(c0, 0, s + 3 < n_steps, false);
+            mma_all(c0);
+        }
+        if (s + 3 < n_steps) {
+            prepare(c1, 1, false, false);
+            mma_all(c1);
+        }
     }
     // the tail: fewer than sixteen points, loads predicated per lane and point
     const int64_t p_tail = p_begin + 16 * (int64_t)n_steps;
