@@ -365,22 +365,75 @@ __device__ __forceinline__ void dma_read_set(PairSet& r, unsigned addr) {
     }
 }
 
+template <int U>
+struct UnitTag {
+    static constexpr int value = U;
+};
+template <int LO, int HI, class F>
+__device__ __forceinline__ void unit_for(F&& f) {
+    if constexpr (LO < HI) {
+        f(UnitTag<LO>{});
+        unit_for<LO + 1, HI>(f);
+    }
+}
+
 // A step's operands split into fp16 (hi, lo) fragments: what its 48 MFMAs read
 struct PairConv {
     u32x4 ahi[4], alo[4], bhi[4], blo[4];
 };
-// unit u of the sixteen a step's split is made of: feature t = u / 4 of the point pairs (2 q, 2 q + 1), q = u % 4, both operands
-__device__ __forceinline__ void pair_convert_unit(PairConv& c, const PairSet& r, int u, float sa, float sb, float (&asum)[4]) {
-    const int t = u >> 2, q = u & 3;
-    const float a0 = r.a[2 * q][t], a1 = r.a[2 * q + 1][t];
-    asum[t] += a0 + a1;
-    unsigned hi, lo;
-    pair_split(a0 * sa, a1 * sa, hi, lo);
-    c.ahi[t][q] = hi;
-    c.alo[t][q] = lo;
-    pair_split(r.b[2 * q][t] * sb, r.b[2 * q + 1][t] * sb, hi, lo);
-    c.bhi[t][q] = hi;
-    c.blo[t][q] = lo;
+// two pairs at once - one of each operand: two independent chains interleaved, so that no instruction reads what the one before it
+// wrote and the two half-register writes of a pair's low halves are an instruction apart (what pair_split buys with an s_nop)
+__device__ __forceinline__ void pair_split2(float a0, float a1, float b0, float b1, unsigned& ahi, unsigned& alo, unsigned& bhi,
+                                            unsigned& blo) {
+    asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_cvt_pk_f16_f32 %2, %6, %7\n\t"
+        "v_fma_mixlo_f16 %1, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %2, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %2, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(ahi), "=&v"(alo), "=&v"(bhi), "=&v"(blo)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+}
+typedef float f32x2u __attribute__((ext_vector_type(2)));
+// a quad times a power of two, as two packed multiplies (hipcc chose scalar ones for two thirds of them)
+__device__ __forceinline__ void scale_quad(f32x4u& x, float s) {
+    f32x2u lo = {x[0], x[1]}, hi = {x[2], x[3]};
+    const f32x2u ss = {s, s};
+    asm("v_pk_mul_f32 %0, %0, %1" : "+v"(lo) : "v"(ss));
+    asm("v_pk_mul_f32 %0, %0, %1" : "+v"(hi) : "v"(ss));
+    x = f32x4u{lo[0], lo[1], hi[0], hi[1]};
+}
+// unit u of the sixteen a step's split is made of: the point pair (2 q, 2 q + 1), q = u / 4, feature t = u % 4, both operands.
+// A pair's first unit (t = 0) adds its two points' dY to the bias sums (all four features: two packed adds each way, in the
+// order the scalar loop added them) and scales both operands' quads IN PLACE (packed multiplies: powers of two); the other
+// three find them scaled. The kernel issues one instruction per ~7 cycles with its one wave per SIMD - it is bound by their
+// NUMBER (profiles/r04_ab_notes.txt) - and this is 9 per pair of values where the scalar form was 15.
+__device__ __forceinline__ void pair_convert_unit(PairConv& c, PairSet& r, int u, float sa, float sb, f32x2u (&asum)[2], bool sums) {
+    const int q = u >> 2, t = u & 3;
+    if (t == 0) {
+        f32x4u &x0 = r.a[2 * q], &x1 = r.a[2 * q + 1];
+        // (all waves add, though only those of the first column half store: a branch per unit costs the ones that do more than
+        // four instructions cost the others; volatile: hipcc otherwise gathers a whole loop body's sums behind its last MFMA, with
+        // copies of the unscaled values)
+        (void)sums;
+        f32x2u lo, hi;
+        asm volatile("v_pk_add_f32 %2, %4, %5\n\t"
+                     "v_pk_add_f32 %3, %6, %7\n\t"
+                     "v_pk_add_f32 %0, %0, %2\n\t"
+                     "v_pk_add_f32 %1, %1, %3"
+                     : "+v"(asum[0]), "+v"(asum[1]), "=&v"(lo), "=&v"(hi)
+                     : "v"(f32x2u{x0[0], x0[1]}), "v"(f32x2u{x1[0], x1[1]}), "v"(f32x2u{x0[2], x0[3]}), "v"(f32x2u{x1[2], x1[3]}));
+        scale_quad(x0, sa);
+        scale_quad(x1, sa);
+        scale_quad(r.b[2 * q], sb);
+        scale_quad(r.b[2 * q + 1], sb);
+    }
+    unsigned ahi, alo, bhi, blo;
+    pair_split2(r.a[2 * q][t], r.a[2 * q + 1][t], r.b[2 * q][t], r.b[2 * q + 1][t], ahi, alo, bhi, blo);
+    c.ahi[t][q] = ahi;
+    c.alo[t][q] = alo;
+    c.bhi[t][q] = bhi;
+    c.blo[t][q] = blo;
 }
 // accumulator tile g = 4 tm + tn of the wave's sixteen: its three products, smallest first
 __device__ __forceinline__ void pair_mma_tile(f32x16 (&acc)[4][4], const PairConv& c, int g) {
@@ -404,8 +457,13 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
     const int c_base = n_begin + 128 * wn;       // this wave's first column
     if (c_base >= n_end) return;
     const int col = c_base + 4 * i;
+#ifdef NERF_EXP_DW_SAMESLICE      // timing experiment (profiles/r04_ab_notes.txt): every workgroup reads slice 0's points - out of L2
+    const int64_t p_begin = 0;
+    int64_t p_end = b.pts_per_slice;
+#else
     const int64_t p_begin = (int64_t)slice * b.pts_per_slice;
     int64_t p_end = p_begin + b.pts_per_slice;
+#endif
     if (p_end > b.P) p_end = b.P;
     const int64_t n_pts = p_end > p_begin ? p_end - p_begin : 0;
     const int n_steps = (int)(n_pts / 16);
@@ -420,7 +478,8 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
-    float asum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x2u asum[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};      // bias sums of the wave's four row tiles (only the waves that store them add)
+    const bool sums = g.db != nullptr && wn == 0;      // (wave-uniform)
     // the rider row (GradJob::y): the waves of the first row half hold X of their 128 columns anyway
     const bool has_y = g.y != nullptr && wm == 0;      // (wave-uniform)
     float ysum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ybias = 0.0f;
@@ -446,10 +505,30 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
     // pieces 8..15, this lane's point octet (8 kh) and half-wave (i % 2)
     const unsigned my_addr = BLK ? my_lds + ((i >> 1) & 7) * kDmaImage + (i >> 4) * 512 + kh * 256 + (i & 1) * 16 : my_lds + lane * 16;
 
+    // BLK: the addresses of a step's loads differ by the lane's constant part (one VGPR for both operands), a wave-uniform base per
+    // operand that moves from step to step (scalar registers; + 4 KiB so that the eight loads' j KiB fit the signed immediate)
+    // and the immediate - no vector instruction per load, where a pointer per lane cost a 64-bit add each. The immediate moves
+    // the LDS address as well: M0 = the image's place minus it. (Every LDS-DMA of this instantiation is such a statement: hipcc
+    // never owns M0 here.)
+    const unsigned v_lane = (unsigned)(kh * 8192 + i * 16);
+    const char* sa_base = nullptr;
+    const char* sb_base = nullptr;
+    if constexpr (BLK) {
+        sa_base = (const char*)(g.A + (p_begin >> 5) * (32 * (int64_t)g.Mo) + ((p_begin >> 4) & 1) * 128 + (m_base >> 3) * 256) + 4096;
+        sb_base = (const char*)(g.B + (p_begin >> 5) * (32 * (int64_t)256) + ((p_begin >> 4) & 1) * 128 + (b_feat0 >> 3) * 256) + 4096;
+    }
+    const unsigned v_lane_y = (unsigned)((lane & 15) * g.ldy * 4);
+    const char* sy_base = has_y ? (const char*)(g.y + p_begin * g.ldy) : nullptr;
     // load u of the sixteen of the step at (pa, pb) into `slot`: a's eight in the order the old loop issued them pairwise with b's
-    auto issue_one = [&](int slot, int u) {
+    auto issue_one = [&](int slot, auto U) {
+        constexpr int u = decltype(U)::value, j = u >> 1;
         char* base = my + slot * kDmaSlotBytes;
-        const int j = u >> 1;
+        if constexpr (BLK) {
+            const unsigned m0 = my_lds + slot * kDmaSlotBytes + ((u & 1) ? 8 + j : j) * kDmaImage - (j * 1024 - 4096);
+            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                         : : "v"(v_lane), "s"((u & 1) ? sb_base : sa_base), "s"(m0), "n"(j * 1024 - 4096) : "memory");
+            return;
+        }
         if ((u & 1) == 0)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + j * load_a),
                                              (__attribute__((address_space(3))) void*)(base + j * kDmaImage), 16, 0, 0);
@@ -459,13 +538,19 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
     };
     auto issue_done = [&](int slot) {      // behind the sixteen: the rider's load, the pointers on to the next step
         if (has_y) {      // lane l fetches y of point (l & 15) of the step: LDS [16 floats] x 4 copies
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)py,
-                                             (__attribute__((address_space(3))) void*)(my + slot * kDmaSlotBytes + kDmaRiderOff), 4, 0, 0);
-            py += step_y;
+            if constexpr (BLK) {
+                asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1"
+                             : : "v"(v_lane_y), "s"(sy_base), "s"(my_lds + slot * kDmaSlotBytes + kDmaRiderOff) : "memory");
+                sy_base += 4 * step_y;
+            } else {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)py,
+                                                 (__attribute__((address_space(3))) void*)(my + slot * kDmaSlotBytes + kDmaRiderOff), 4, 0, 0);
+                py += step_y;
+            }
         }
         if constexpr (BLK) {
-            pa += half ? group_a : 128;
-            pb += half ? group_b : 128;
+            sa_base += 4 * (half ? group_a : 128);
+            sb_base += 4 * (half ? group_b : 128);
             half ^= 1;
         } else {
             pa += step_a;
@@ -473,8 +558,7 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
         }
     };
     auto issue = [&](int slot) {      // the sixteen loads of the step at (pa, pb) into `slot`
-#pragma unroll
-        for (int u = 0; u < 16; ++u) issue_one(slot, u);
+        unit_for<0, 16>([&](auto U) { issue_one(slot, U); });
         issue_done(slot);
     };
     auto ride = [&](const PairSet& r, const f32x4u& y0, const f32x4u& y1) {      // y of this lane's eight points
@@ -498,7 +582,7 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float a0 = r.a[2 * q][t], a1 = r.a[2 * q + 1][t];
-                asum[t] += a0 + a1;
+                asum[t >> 1][t & 1] += a0 + a1;
                 unsigned hi, lo;
                 pair_split(a0 * sa, a1 * sa, hi, lo);
                 ahi[t][q] = hi;
@@ -552,7 +636,7 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
         __builtin_amdgcn_sched_barrier(0);
         if (has_y) ride(r, y0, y1);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) pair_convert_unit(c, r, u, sa, sb, asum);
+        for (int u = 0; u < 16; ++u) pair_convert_unit(c, r, u, sa, sb, asum, sums);
     };
     auto mma_all = [&](const PairConv& c) {
 #pragma unroll
@@ -571,19 +655,20 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (has_y) ride(r, y0, y1);
-#pragma unroll
-        for (int g = 2; g < 16; ++g) {
+        unit_for<2, 16>([&](auto G) {
+            constexpr int g = decltype(G)::value;
             pair_mma_tile(acc, cur, g);
             // sixteen units of splitting and sixteen loads behind fourteen tiles: two each behind the first two
-            const int u0 = g < 4 ? 2 * (g - 2) : g, n_u = g < 4 ? 2 : 1;
-#pragma unroll
-            for (int k = 0; k < n_u; ++k) {
-                pair_convert_unit(nxt, r, u0 + k, sa, sb, asum);
-                issue_one(slot, u0 + k);
+            constexpr int u0 = g < 4 ? 2 * (g - 2) : g;
+            pair_convert_unit(nxt, r, u0, sa, sb, asum, sums);
+            issue_one(slot, UnitTag<u0>{});
+            if constexpr (g < 4) {
+                pair_convert_unit(nxt, r, u0 + 1, sa, sb, asum, sums);
+                issue_one(slot, UnitTag<u0 + 1>{});
             }
-            if (g == 15) issue_done(slot);
+            if constexpr (g == 15) issue_done(slot);
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
     };
 
     if (n_steps > 0) {
@@ -660,7 +745,7 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
     if (g.db && wn == 0) {
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm) {
-            const float t = asum[tm] + __shfl_xor(asum[tm], 32);
+            const float t = asum[tm >> 1][tm & 1] + __shfl_xor(asum[tm >> 1][tm & 1], 32);
             if (kh == 0) g.dbp[(int64_t)slice * g.Mo + m_base + 4 * i + tm] = t;
         }
     }
