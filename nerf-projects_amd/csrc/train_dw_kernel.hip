@@ -410,6 +410,7 @@ __device__ __forceinline__ void scale_quad(f32x4u& x, float s) {
 // NUMBER (profiles/r04_ab_notes.txt) - and this is 9 per pair of values where the scalar form was 15.
 __device__ __forceinline__ void pair_convert_unit(PairConv& c, PairSet& r, int u, float sa, float sb, f32x2u (&asum)[2], bool sums) {
     const int q = u >> 2, t = u & 3;
+#ifndef NERF_EXP_DW_NOCONV
     if (t == 0) {
         f32x4u &x0 = r.a[2 * q], &x1 = r.a[2 * q + 1];
         // (all waves add, though only those of the first column half store: a branch per unit costs the ones that do more than
@@ -428,8 +429,14 @@ __device__ __forceinline__ void pair_convert_unit(PairConv& c, PairSet& r, int u
         scale_quad(r.b[2 * q], sb);
         scale_quad(r.b[2 * q + 1], sb);
     }
+#endif
     unsigned ahi, alo, bhi, blo;
+#ifdef NERF_EXP_DW_NOCONV      // ... without the (hi, lo) split ...
+    ahi = __float_as_uint(r.a[2 * q][t]); alo = __float_as_uint(r.a[2 * q + 1][t]);
+    bhi = __float_as_uint(r.b[2 * q][t]); blo = __float_as_uint(r.b[2 * q + 1][t]);
+#else
     pair_split2(r.a[2 * q][t], r.a[2 * q + 1][t], r.b[2 * q][t], r.b[2 * q + 1][t], ahi, alo, bhi, blo);
+#endif
     c.ahi[t][q] = ahi;
     c.alo[t][q] = alo;
     c.bhi[t][q] = bhi;
@@ -438,6 +445,10 @@ __device__ __forceinline__ void pair_convert_unit(PairConv& c, PairSet& r, int u
 // accumulator tile g = 4 tm + tn of the wave's sixteen: its three products, smallest first
 __device__ __forceinline__ void pair_mma_tile(f32x16 (&acc)[4][4], const PairConv& c, int g) {
     const int tm = g >> 2, tn = g & 3;
+#ifdef NERF_EXP_DW_NOMMA      // timing experiments (profiles/r04_ab_notes.txt): the step without its MFMAs ...
+    asm volatile("" ::"v"(c.alo[tm]), "v"(c.bhi[tn]), "v"(c.ahi[tm]), "v"(c.blo[tn]));
+    return;
+#endif
     acc[tm][tn] = mfma16h(c.alo[tm], c.bhi[tn], acc[tm][tn]);
     acc[tm][tn] = mfma16h(c.ahi[tm], c.blo[tn], acc[tm][tn]);
     acc[tm][tn] = mfma16h(c.ahi[tm], c.bhi[tn], acc[tm][tn]);
@@ -523,6 +534,12 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
     auto issue_one = [&](int slot, auto U) {
         constexpr int u = decltype(U)::value, j = u >> 1;
         char* base = my + slot * kDmaSlotBytes;
+#ifdef NERF_EXP_DW_NOLOAD      // ... without its loads (the LDS images stay what they were)
+        return;
+#endif
+#ifdef NERF_EXP_DW_NODUP       // ... with only the half of its loads no other wave of the workgroup issues too (timing of a shared ring)
+        if (((u & 1) == 0 && (j >> 2) != wn) || ((u & 1) == 1 && (j >> 2) != wm)) return;
+#endif
         if constexpr (BLK) {
             const unsigned m0 = my_lds + slot * kDmaSlotBytes + ((u & 1) ? 8 + j : j) * kDmaImage - (j * 1024 - 4096);
             asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
@@ -537,7 +554,12 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
                                              (__attribute__((address_space(3))) void*)(base + 8 * kDmaImage + j * kDmaImage), 16, 0, 0);
     };
     auto issue_done = [&](int slot) {      // behind the sixteen: the rider's load, the pointers on to the next step
-        if (has_y) {      // lane l fetches y of point (l & 15) of the step: LDS [16 floats] x 4 copies
+#ifdef NERF_EXP_DW_NOLOAD
+        if (false)
+#else
+        if (has_y)      // lane l fetches y of point (l & 15) of the step: LDS [16 floats] x 4 copies
+#endif
+        {
             if constexpr (BLK) {
                 asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1"
                              : : "v"(v_lane_y), "s"(sy_base), "s"(my_lds + slot * kDmaSlotBytes + kDmaRiderOff) : "memory");
@@ -611,9 +633,17 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
     // same order: bit-identical sums.
     // wait: step k has landed when at most the loads of the step issued after it are outstanding
     auto await = [&](bool newer_in_flight) {
+#ifdef NERF_EXP_DW_NOLOAD
+        return;
+#endif
         if (!newer_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef NERF_EXP_DW_NODUP
+        else if (has_y) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#else
         else if (has_y) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");      // (a step of a wave with the rider is 17 loads)
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#endif
     };
     auto read_back = [&](PairSet& r, f32x4u& y0, f32x4u& y1, int slot) {
         dma_read_set<0, BLK>(r, my_addr + slot * kDmaSlotBytes);
@@ -654,6 +684,10 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
         pair_mma_tile(acc, cur, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+#ifdef NERF_EXP_DW_EARLY      // timing experiment: the loads of step s + 3 all at once, as soon as the slot is free
+        issue(slot);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (has_y) ride(r, y0, y1);
         unit_for<2, 16>([&](auto G) {
             constexpr int g = decltype(G)::value;
@@ -661,12 +695,18 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
             // sixteen units of splitting and sixteen loads behind fourteen tiles: two each behind the first two
             constexpr int u0 = g < 4 ? 2 * (g - 2) : g;
             pair_convert_unit(nxt, r, u0, sa, sb, asum, sums);
+#ifndef NERF_EXP_DW_EARLY
             issue_one(slot, UnitTag<u0>{});
+#endif
             if constexpr (g < 4) {
                 pair_convert_unit(nxt, r, u0 + 1, sa, sb, asum, sums);
+#ifndef NERF_EXP_DW_EARLY
                 issue_one(slot, UnitTag<u0 + 1>{});
+#endif
             }
+#ifndef NERF_EXP_DW_EARLY
             if constexpr (g == 15) issue_done(slot);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
     };
