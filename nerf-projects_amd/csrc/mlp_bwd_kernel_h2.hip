@@ -187,6 +187,10 @@ void nerf_mlp_bwd_h2_kernel(const MlpBwdLaunch b) {
     }
     const unsigned rgb0 = lds_addr(rgb_lds) + 64 * h;   // this half-wave's entries of tile 0 of row 0 (row c, tile t: + 128 (4 c + t))
 
+#ifdef NERF_EXP_STAGGER      // timing experiment (profiles/r04_ab_notes.txt): workgroups out of phase with each other, so that the chip's
+    // thousand waves do not issue their stores (and their weight-stream loads) in the same instants
+    for (int k = 0; k < (int)((blockIdx.x >> 3) & 7); ++k) __builtin_amdgcn_s_sleep(NERF_EXP_STAGGER);
+#endif
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         pipe_tile_start(pipe);
         const int64_t pt = point_of(tile);

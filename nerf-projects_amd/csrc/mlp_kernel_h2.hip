@@ -394,6 +394,10 @@ void nerf_mlp_h2_kernel(const MlpLaunch a) {
     const unsigned bias0 = lds_addr(bias_lds) + 64 * h;   // this half-wave's entries of bias-block tile 0
     const int n_layers = a.use_viewdirs ? a.D + 1 : a.D;
     const int64_t n_tiles = (a.n_points + kPointsPerGroup - 1) / kPointsPerGroup;
+#ifdef NERF_EXP_STAGGER      // timing experiment (profiles/r04_ab_notes.txt): workgroups out of phase with each other, so that the chip's
+    // thousand waves do not issue their stores (and their weight-stream loads) in the same instants
+    for (int k = 0; k < (int)((blockIdx.x >> 3) & 7); ++k) __builtin_amdgcn_s_sleep(NERF_EXP_STAGGER);
+#endif
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 #ifdef NERF_STAMPS
         pipe.c = 0;
