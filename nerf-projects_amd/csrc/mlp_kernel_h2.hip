@@ -106,7 +106,7 @@ __device__ __forceinline__ void keep_pairs(const Pending& pd, const f32x2& even,
     // (s_nop 1: a store of more than 8 bytes reads its data registers late - two wait states before a vector instruction
     // may overwrite them on gfx950; hipcc's hazard recogniser does not look inside inline asm)
     if constexpr (STORE == 2) {
-        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1"
+        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 " NERF_STORE_BITS "\n\ts_nop 1"
                      :
                      : "v"(pd.keep_off), "v"(v), "s"(pd.keep_base), "n"(1024 * Q - ((T & 1) ? 0 : 4096))
                      : "memory");

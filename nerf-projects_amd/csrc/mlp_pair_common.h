@@ -449,6 +449,18 @@ template <int IMM>
 __device__ __forceinline__ void keep_quad(float* base, unsigned off, const f32x4& v) {
     asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base), "n"(IMM) : "memory");
 }
+// cache-policy bits of the blocked layout's stores (timing experiments set others: profiles/r04_ab_notes.txt)
+#if defined(NERF_STORE_BITS_SEL) && NERF_STORE_BITS_SEL == 1
+#define NERF_STORE_BITS "sc1 nt"
+#elif defined(NERF_STORE_BITS_SEL) && NERF_STORE_BITS_SEL == 2
+#define NERF_STORE_BITS "sc0 nt"
+#elif defined(NERF_STORE_BITS_SEL) && NERF_STORE_BITS_SEL == 3
+#define NERF_STORE_BITS "sc1"
+#elif defined(NERF_STORE_BITS_SEL) && NERF_STORE_BITS_SEL == 4
+#define NERF_STORE_BITS "sc0 sc1 nt"
+#else
+#define NERF_STORE_BITS "nt"
+#endif
 // the same with the nt bit, for stores that write whole lines of data nobody reads soon (the layout blocked by 32 points)
 template <int IMM>
 __device__ __forceinline__ void keep_quad_nt(float* base, unsigned off, const f32x4& v) {
@@ -456,7 +468,7 @@ __device__ __forceinline__ void keep_quad_nt(float* base, unsigned off, const f3
     asm volatile("" ::"v"(v), "v"(off), "s"(base));
     return;
 #endif
-    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base), "n"(IMM) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 " NERF_STORE_BITS "\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base), "n"(IMM) : "memory");
 }
 template <int IMM>
 __device__ __forceinline__ void keep_word(unsigned* base, unsigned off, unsigned v) {
