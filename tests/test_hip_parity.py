@@ -1478,8 +1478,8 @@ g = np.load(sys.argv[1] + "/tests/golden/train_step.npz")
 if views:
     sd_c, sd_f = synthetic.synthetic_pair(0)
     mk = dict(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True)
-else:      # nerf.ipynb:879-885: no view directions, a 5-channel output_linear
-    arch = dict(input_ch_views=0, use_viewdirs=False, output_ch=5)
+else:      # nerf.ipynb:879-885: no view directions, output_linear of 5 channels (4 without a fine pass)
+    arch = dict(input_ch_views=0, use_viewdirs=False, output_ch=5 if n_imp else 4)
     sd_c, sd_f = synthetic.synthetic_state_dict(8, **arch), synthetic.synthetic_state_dict(48, **arch)
     mk = dict(D=8, W=256, input_ch=63, skips=[4], **arch)
 net_c, net_f = N.NeRF(**mk).load_state_dict(sd_c), N.NeRF(**mk).load_state_dict(sd_f)
@@ -1507,7 +1507,8 @@ np.savez(out_path, **res)
 @pytest.mark.parametrize("n_imp,switch,views", [(128, "NERF_TRAIN_GLUE=legacy", "views"), (0, "NERF_TRAIN_GLUE=legacy", "views"),
                                                 (128, "NERF_TRAIN_NARROW=f32 NERF_TRAIN_BLOCKED=0", "views"),
                                                 (128, "NERF_TRAIN_GLUE=legacy", "noviews"),
-                                                (128, "NERF_TRAIN_NARROW=f32 NERF_TRAIN_BLOCKED=0", "noviews")])
+                                                (128, "NERF_TRAIN_NARROW=f32 NERF_TRAIN_BLOCKED=0", "noviews"),
+                                                (0, "NERF_TRAIN_NARROW=f32 NERF_TRAIN_BLOCKED=0", "noviews")])
 def test_train_glue_is_bit_identical(N, n_imp, switch, views, tmp_path):
     """Two optimiser steps on the reference's fixture batch, twice: as shipped, and with one of the step's A/B switches thrown
     (each needs a process of its own: the switches are read once) - every loss, PSNR, colour, gradient and weight bit for bit.
