@@ -29,13 +29,23 @@ def main():
     p.add_argument("--samples", type=int, default=64)
     p.add_argument("--importance", type=int, default=128)
     p.add_argument("--no-viewdirs", action="store_true", help="networks without view directions (use_viewdirs=False, 5-channel head)")
+    p.add_argument("--only", action="store_true", help="no second, short run of create_nerf's other branch (train_noviewdirs)")
     a = p.parse_args()
+    torch.cuda.set_device(0)
+    res = run(a, a.no_viewdirs, a.iters, a.warmup, True)
+    if not a.no_viewdirs and not a.only:      # create_nerf's other branch (nerf.ipynb:885-896), 20 iterations of it
+        nv = run(a, True, 20, 3, False)
+        res["train_noviewdirs"] = {"value": nv["value"], "unit": "it/s", "ms_per_iter": nv["ms_per_iter"], "iters": 20,
+                                   "model": "use_viewdirs=False, output_ch=5"}
+    print(json.dumps(res))
+
+
+def run(a, no_viewdirs, iters, warmup, spans_wanted):
     import nerf_projects_amd as N
     from nerf_projects_amd import synthetic
-    torch.cuda.set_device(0)
     sd_c, sd_f = synthetic.synthetic_pair(0)
     mk = dict(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
-    if a.no_viewdirs:
+    if no_viewdirs:
         mk.update(input_ch_views=0, use_viewdirs=False)
         sd_c, sd_f = (synthetic.synthetic_state_dict(s, input_ch_views=0, use_viewdirs=False, output_ch=5) for s in (8, 48))
     net_c, net_f = N.NeRF(**mk).load_state_dict(sd_c), N.NeRF(**mk).load_state_dict(sd_f)
@@ -43,7 +53,7 @@ def main():
     K, c2w, near, far = synthetic.lego_camera(800, 800)
     packed = N.generate_rays(800, 800, K, c2w, ndc=False, near=near, far=far, use_viewdirs=True)
     kw = dict(network_fn=net_c, network_fine=net_f, N_samples=a.samples, N_importance=a.importance, white_bkgd=True,
-              perturb=1.0, raw_noise_std=1.0, ndc=False, use_viewdirs=not a.no_viewdirs, near=near, far=far)
+              perturb=1.0, raw_noise_std=1.0, ndc=False, use_viewdirs=not no_viewdirs, near=near, far=far)
     torch.manual_seed(0)
     lrate, lrate_decay = 5e-4, 500
 
@@ -64,32 +74,34 @@ def main():
         opt.param_groups[0]['lr'] = lrate * (0.1 ** (i / (lrate_decay * 1000)))     # nerf.ipynb:1278-1282
         return out
 
-    for i in range(a.warmup):
+    for i in range(warmup):
         one(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.iters):
+    for i in range(iters):
         out = one(i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     evals = a.n_rand * (a.samples + (a.samples + a.importance if a.importance else 0))
     flops = evals * 1186816 * 3          # forward + dX + dW
     # the step's big kernels by kind (HIP events on the step's stream, a short second run: not inside the reported it/s)
-    ctx = N.get_context()
-    ctx.profile_enable(True)
-    ctx.profile_read_train(reset=True)
-    for i in range(10):
-        one(i)
-    torch.cuda.synchronize()
-    ctx.profile_enable(False)
-    spans = {k: {"ms_per_iter": v[0] / 10, "launches_per_iter": v[1] / 10} for k, v in ctx.profile_read_train(reset=True).items()}
-    print(json.dumps({"metric": "train_iterations_per_sec", "value": a.iters / dt, "unit": "it/s", "kernels": spans,
-                      "ms_per_iter": dt / a.iters * 1e3, "n_rand": a.n_rand, "N_samples": a.samples,
-                      "N_importance": a.importance, "mlp_evals_per_iter": evals,
-                      "approx_tflops": flops * a.iters / dt / 1e12, "final_loss": float(out["loss"]),
-                      "forward_arithmetic": ("f32" if os.environ.get("NERF_TRAIN_FORWARD", "").lower().startswith("f3") or
-                                             N.get_context().get_precision() != "f16x2" else "f16x2 (fp16-pair kernel)"),
-                      "reference_stored_run_it_per_s": "5.6-7.4 (ship 96+192, unknown CUDA GPU; BASELINE.md)"}))
+    spans = {}
+    if spans_wanted:
+        ctx = N.get_context()
+        ctx.profile_enable(True)
+        ctx.profile_read_train(reset=True)
+        for i in range(10):
+            one(i)
+        torch.cuda.synchronize()
+        ctx.profile_enable(False)
+        spans = {k: {"ms_per_iter": v[0] / 10, "launches_per_iter": v[1] / 10} for k, v in ctx.profile_read_train(reset=True).items()}
+    return {"metric": "train_iterations_per_sec", "value": iters / dt, "unit": "it/s", "kernels": spans,
+            "ms_per_iter": dt / iters * 1e3, "n_rand": a.n_rand, "N_samples": a.samples,
+            "N_importance": a.importance, "mlp_evals_per_iter": evals,
+            "approx_tflops": flops * iters / dt / 1e12, "final_loss": float(out["loss"]),
+            "forward_arithmetic": ("f32" if os.environ.get("NERF_TRAIN_FORWARD", "").lower().startswith("f3") or
+                                   N.get_context().get_precision() != "f16x2" else "f16x2 (fp16-pair kernel)"),
+            "reference_stored_run_it_per_s": "5.6-7.4 (ship 96+192, unknown CUDA GPU; BASELINE.md)"}
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ PART=${1:-all}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/measure; mkdir -p $O   # (clear the local gpurun_out/measure first: gpurun merges, it does not mirror)
 cd /tmp; export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-precision --no-train"
-T="python3 $R/bench_train.py --iters 12 --warmup 3"
+T="python3 $R/bench_train.py --iters 12 --warmup 3 --only"
 PMC_SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 PMC_L2="GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"
 pmc() { timeout -k 10 240 rocprofv3 --pmc $1 --kernel-trace --output-format csv -d $O/$2 -- $3 > $O/$2.log 2>&1; }
@@ -26,12 +26,12 @@ pmc "$PMC_SQ" pmc_sq "$B" && echo s ok && pmc "$PMC_L2" pmc_l2 "$B" && echo l ok
 fi
 if [ $PART = train ] || [ $PART = all ]; then
 timeout -k 10 200 python3 $R/bench_train.py --iters 60 > $O/bench_train.json 2>> $O/bench_n1.err && echo train ok &&
-NERF_TRAIN_BLOCKED=0 timeout -k 10 200 python3 $R/bench_train.py --iters 60 > $O/bench_train_rowmajor.json 2>> $O/bench_n1.err && echo train row-major ok &&
-NERF_TRAIN_GLUE=legacy timeout -k 10 200 python3 $R/bench_train.py --iters 60 > $O/bench_train_legacy_glue.json 2>> $O/bench_n1.err && echo train legacy glue ok &&
+NERF_TRAIN_BLOCKED=0 timeout -k 10 200 python3 $R/bench_train.py --iters 60 --only > $O/bench_train_rowmajor.json 2>> $O/bench_n1.err && echo train row-major ok &&
+NERF_TRAIN_GLUE=legacy timeout -k 10 200 python3 $R/bench_train.py --iters 60 --only > $O/bench_train_legacy_glue.json 2>> $O/bench_n1.err && echo train legacy glue ok &&
 timeout -k 10 200 python3 $R/bench_train.py --iters 60 --no-viewdirs > $O/bench_train_noviewdirs.json 2>> $O/bench_n1.err && echo train no-viewdirs ok &&
-NERF_TRAIN_BWD=f32 timeout -k 10 200 python3 $R/bench_train.py --iters 60 > $O/bench_train_bwd_f32.json 2>> $O/bench_n1.err && echo train bwd-f32 ok &&
-NERF_PRECISION=f32 timeout -k 10 200 python3 $R/bench_train.py --iters 40 > $O/bench_train_all_f32.json 2>> $O/bench_n1.err && echo train f32 ok &&
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -- python3 $R/bench_train.py --iters 20 --warmup 3 > $O/train_stats.log 2>&1 && echo train stats ok &&
+NERF_TRAIN_BWD=f32 timeout -k 10 200 python3 $R/bench_train.py --iters 60 --only > $O/bench_train_bwd_f32.json 2>> $O/bench_n1.err && echo train bwd-f32 ok &&
+NERF_PRECISION=f32 timeout -k 10 200 python3 $R/bench_train.py --iters 40 --only > $O/bench_train_all_f32.json 2>> $O/bench_n1.err && echo train f32 ok &&
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -- python3 $R/bench_train.py --iters 20 --warmup 3 --only > $O/train_stats.log 2>&1 && echo train stats ok &&
 pmc "FETCH_SIZE" train_pmc_fetch "$T" && pmc "WRITE_SIZE" train_pmc_write "$T" && pmc "$PMC_SQ" train_pmc_sq "$T" && pmc "$PMC_L2" train_pmc_l2 "$T" && echo train pmc ok &&
 true || exit 1
 fi

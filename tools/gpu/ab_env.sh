@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
 for envset in "$@"; do
   for rep in 1 2; do
-    ( [ "$envset" != "-" ] && export $envset; timeout -k 10 200 python3 $R/bench_train.py --iters 80 2>/dev/null | tail -1 | python3 -c "
+    ( [ "$envset" != "-" ] && export $envset; timeout -k 10 200 python3 $R/bench_train.py --iters 80 --only 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 k=d.get('kernels',{})

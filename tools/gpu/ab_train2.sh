@@ -6,7 +6,7 @@ for v in "$@"; do
   if [ $v = A ]; then L=$R/nerf-projects_amd/libnerf_mi355x.so; else L=$R/nerf-projects_amd/variants/lib$v.so; fi
   export NERF_MI355X_LIB=$L
   for rep in 1 2; do
-    timeout -k 10 200 python3 $R/bench_train.py --iters 80 2>/dev/null | tail -1 | python3 -c "
+    timeout -k 10 200 python3 $R/bench_train.py --iters 80 --only 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 k=d.get('kernels',{})
