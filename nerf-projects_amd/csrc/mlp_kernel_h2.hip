@@ -977,8 +977,8 @@ __global__ __launch_bounds__(kRowExpThreads) void row_exponents_kernel(const Equ
 // factors are its producer's row factors - but only the arithmetic depends on them, not the loads: every workgroup fetches its
 // layer's weights into registers at once (sixteen rows per wave, all of them in flight), THEN waits for its producer's flag in
 // memory, reads the producer's exponents and finishes in a few microseconds. The chain's latency is a flag, sixteen rows of
-// arithmetic, a histogram and a median per layer instead of a layer's worth of memory latency: 0.10 -> 0.03 ms per training
-// iteration. Same expressions in the same order per row as row_exponents_kernel: the same table, bit for bit. All r.n x n
+// arithmetic, a histogram and a median per layer instead of a layer's worth of memory latency: 105 -> 83 us per training
+// iteration for both networks (profiles/r04_train_kernel_stats.csv). Same expressions in the same order per row as row_exponents_kernel: the same table, bit for bit. All r.n x n
 // workgroups are resident at once (two dozen on 256 CUs), so the waiting ones cannot starve their producers; the mailbox words
 // carry the launch's epoch (24 bits) and need no reset.
 __global__ __launch_bounds__(kRowExpThreads) void row_exponents_layers_kernel(const EqualiseBatch batch) {

@@ -626,8 +626,8 @@ void grad_batch_pair_dma_kernel(const GradBatch b) {
     // A step = 48 MFMAs (1 536 matrix-pipe cycles) + its preparation: sixteen reads back from LDS, sixteen loads of the step two
     // ahead into the slot just read, ~240 vector instructions of scaling and (hi, lo) splitting. One after the other - what hipcc
     // makes of a loop body written that way, with one wave per SIMD and nobody else to issue - a step took ~4 000 cycles and the
-    // matrix pipe was busy 38 % of them (profiles/r04_train_pmc_summary.md, round 4): the kernel ran at 4.8 TB/s without being
-    // bound by memory. So the loop is software-pipelined by hand: while step s's MFMAs run from one register set (PairConv), step
+    // matrix pipe was busy 38 % of them: the kernel ran at 4.8 TB/s of the 6.0 the chip reads at (profiles/microbench/
+    // hbm_read_rate.hip); pipelined it runs at 5.3 (profiles/r04_train_pmc_summary.md). So the loop is software-pipelined by hand: while step s's MFMAs run from one register set (PairConv), step
     // s + 1 is awaited, read back and split into the other, a slice of that work behind every accumulator tile's three MFMAs,
     // the slices fenced (sched_barrier) so that they stay where they are put. Same products into the same accumulators in the
     // same order: bit-identical sums.
